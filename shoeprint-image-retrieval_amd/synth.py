@@ -1,0 +1,117 @@
+"""Seeded synthetic feature maps and shoeprint-like images (host twin).
+
+Neither WVU2019 nor pretrained weights exist offline ("Mismatches"),
+so tests and ``bench.py`` run on WVU2019-*shaped* synthetic data.  Everything is
+derived from one counter-based generator (splitmix64) using integer arithmetic
+and power-of-two scalings only, so the numpy twin here and the HIP generator in
+``csrc/synth.hip`` produce bit-identical float32 values: the GPU box regenerates
+inputs from a seed and only small *outputs* are committed as fixtures.
+
+Feature model (post-ReLU activations, ~50 % zeros like VGG maps):
+
+* gallery item ``g``:  relu(n_g[c,y,x])                         n = Irwin-Hall(4) noise
+* query ``q`` matching gallery item ``m`` with shift (dy,dx):
+      relu((3*n_m[c,y+dy,x+dx] + 2*n'_q[c,y,x]) / 4)            (noise only where the
+                                                                shifted pixel is outside)
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+STREAM_GALLERY = 1
+STREAM_QUERY = 2
+STREAM_SHIFT = 3
+STREAM_IMAGE = 4
+STREAM_WEIGHT = 5
+
+
+def splitmix64(x: np.ndarray | int) -> np.ndarray:
+    """One splitmix64 output for every 64-bit counter in ``x``."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(x, dtype=np.uint64) + _GOLD) & MASK
+        z = ((z ^ (z >> np.uint64(30))) * _M1) & MASK
+        z = ((z ^ (z >> np.uint64(27))) * _M2) & MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def stream_key(seed: int, stream: int, item: int) -> np.uint64:
+    """Key of one item's stream: two chained splitmix64 rounds over (seed, stream, item)."""
+    with np.errstate(over="ignore"):
+        k = splitmix64(np.uint64(seed))
+        k = splitmix64((k ^ (np.uint64(stream) << np.uint64(56))) + np.uint64(item))
+    return np.uint64(k)
+
+
+def irwin_hall_int(key: np.uint64, idx: np.ndarray) -> np.ndarray:
+    """Sum of the four 16-bit fields of splitmix64(key + idx), centred: an int32 in
+    [-131070, 131070] with standard deviation ~37 837 (approximately normal)."""
+    with np.errstate(over="ignore"):
+        r = splitmix64((np.uint64(key) + idx.astype(np.uint64)) & MASK)
+    f = np.uint64(0xFFFF)
+    s = (r & f) + ((r >> np.uint64(16)) & f) + ((r >> np.uint64(32)) & f) + (r >> np.uint64(48))
+    return s.astype(np.int64).astype(np.int32) - np.int32(131070)
+
+
+def gallery_features(seed: int, g: int, c: int, h: int, w: int) -> np.ndarray:
+    """float32 [c,h,w] post-ReLU features of gallery item ``g``."""
+    n = irwin_hall_int(stream_key(seed, STREAM_GALLERY, g), np.arange(c * h * w, dtype=np.int64))
+    return (np.maximum(n, 0).astype(np.float32) * np.float32(1.0 / 32768.0)).reshape(c, h, w)
+
+
+def query_shift(seed: int, q: int, max_shift: int = 3) -> tuple[int, int]:
+    r = int(splitmix64(stream_key(seed, STREAM_SHIFT, q)))
+    span = 2 * max_shift + 1
+    return (r & 0xFFFF) % span - max_shift, ((r >> 16) & 0xFFFF) % span - max_shift
+
+
+def query_features(seed: int, q: int, match: int, c: int, h: int, w: int, max_shift: int = 3,
+                   signal: int = 3, noise: int = 2) -> np.ndarray:
+    """float32 [c,h,w] features of query ``q``: a shifted, noised copy of gallery item ``match``.
+
+    ``signal``/``noise`` are the small integer mixing weights (3, 2 by default; e.g. 1, 6
+    gives a hard set whose true matches are not all ranked first)."""
+    dy, dx = query_shift(seed, q, max_shift)
+    cc, yy, xx = np.meshgrid(np.arange(c), np.arange(h), np.arange(w), indexing="ij")
+    sy, sx = yy + dy, xx + dx
+    inside = (sy >= 0) & (sy < h) & (sx >= 0) & (sx < w)
+    src = (cc * h + np.clip(sy, 0, h - 1)) * w + np.clip(sx, 0, w - 1)
+    base = irwin_hall_int(stream_key(seed, STREAM_GALLERY, match), src.ravel().astype(np.int64)).reshape(c, h, w)
+    noise_i = irwin_hall_int(stream_key(seed, STREAM_QUERY, q), np.arange(c * h * w, dtype=np.int64)).reshape(c, h, w)
+    mix = np.where(inside, signal * base, 0) + noise * noise_i  # |mix| < 2^24: exact in float32
+    return np.maximum(mix, 0).astype(np.float32) * np.float32(1.0 / 131072.0)
+
+
+def default_matches(n_queries: int, n_gallery: int) -> np.ndarray:
+    """Gallery index of every query's true match: spread over the gallery, distinct while Q <= G."""
+    step = max(1, n_gallery // max(1, n_queries))
+    return ((np.arange(n_queries, dtype=np.int64) * step) % n_gallery).astype(np.int32)
+
+
+def dataset(seed: int, n_queries: int, n_gallery: int, c: int, h: int, w: int, signal: int = 3, noise: int = 2):
+    """(query list, gallery list, matching ids) in the reference's list-of-arrays form."""
+    matches = default_matches(n_queries, n_gallery)
+    gallery = [gallery_features(seed, g, c, h, w) for g in range(n_gallery)]
+    queries = [query_features(seed, q, int(matches[q]), c, h, w, signal=signal, noise=noise)
+               for q in range(n_queries)]
+    return queries, gallery, [int(m) for m in matches]
+
+
+def shoeprint_image(seed: int, item: int, h: int = 512, w: int = 256) -> np.ndarray:
+    """uint8 [h,w] shoeprint-like image: low-pass filtered noise thresholded to ~50 % ink
+    with a soft edge (ridge/blob texture), for the extractor tests."""
+    n = irwin_hall_int(stream_key(seed, STREAM_IMAGE, item), np.arange(h * w, dtype=np.int64))
+    f = n.astype(np.float64).reshape(h, w)
+    for axis, k in ((0, 9), (1, 9)):
+        cs = np.cumsum(np.concatenate([np.zeros_like(np.take(f, [0], axis=axis)), f], axis=axis), axis=axis)
+        lo = np.clip(np.arange(f.shape[axis]) - k // 2, 0, f.shape[axis])
+        hi = np.clip(np.arange(f.shape[axis]) - k // 2 + k, 0, f.shape[axis])
+        f = np.take(cs, hi, axis=axis) - np.take(cs, lo, axis=axis)
+    f = f / (np.abs(f).max() + 1e-9)
+    img = 127.5 + 127.5 * np.tanh(6.0 * f)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
