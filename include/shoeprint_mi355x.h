@@ -1,0 +1,151 @@
+/*
+ * shoeprint_mi355x.h — C ABI of the MI355X-native shoeprint retrieval hot path.
+ *
+ * The reference (struan-robertson/shoeprint-image-retrieval) is pure Python and has
+ * no FFI layer of its own; its hot path is entered through the Python call surface
+ * run.py:20-34 uses.  This header is the C-level boundary our host-side mirror of
+ * that surface (shoeprint-image-retrieval_amd/similarity.py, network.py) binds with
+ * ctypes, and what a maintainer of the reference would bind to replace
+ *
+ *   similarity.py:26-72    normxcorr            -> spr_ncc_* (per-channel NCC maps)
+ *   similarity.py:75-108   get_similarity       -> spr_ncc_score (one pair = Q=G=1)
+ *   similarity.py:355-367  score matrix, floor 0, max over variants -> spr_ncc_score
+ *   similarity.py:378-386  _get_rank            -> spr_rank_true_match
+ *   network.py:185-244     truncated VGG16 forward -> spr_vgg16_* (see below)
+ *
+ * (INTEGRATION.md shows the binding stubs.)
+ *
+ * Conventions
+ *  - Every pointer marked "device" is a HIP device pointer owned by the caller
+ *    (PyTorch-ROCm allocations in our host code).  Nothing here allocates or frees
+ *    caller-visible memory, and nothing synchronises the stream: all work is
+ *    enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream).
+ *  - All entry points return SPR_OK (0) or a negative error code; spr_last_error()
+ *    gives the message for the calling thread.
+ *  - Feature maps are dense row-major [item][channel][row][col] ("[N,C,h,w]"),
+ *    float32 unless the plan's dtype says otherwise (customtypes.py:7-14,
+ *    network.py:241).
+ *  - Thread safety: a plan may be used from one host thread at a time; different
+ *    plans are independent.
+ */
+#ifndef SHOEPRINT_MI355X_H
+#define SHOEPRINT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPR_ABI_VERSION 1
+
+enum spr_status {
+  SPR_OK = 0,
+  SPR_ERR_ARG = -1,         /* null pointer, negative count, bad enum */
+  SPR_ERR_SHAPE = -2,       /* shape not representable (e.g. map smaller than the crop) */
+  SPR_ERR_UNSUPPORTED = -3, /* valid request this build has no kernel for */
+  SPR_ERR_HIP = -4,         /* a HIP runtime call or kernel launch failed */
+  SPR_ERR_WORKSPACE = -5    /* caller-provided buffer too small */
+};
+
+enum spr_dtype { SPR_F32 = 0, SPR_F16 = 1, SPR_BF16 = 2 };
+
+/* Which pair kernel scores a (query, gallery) pair. */
+enum spr_ncc_method {
+  SPR_NCC_AUTO = 0,   /* FFT when the padded maps fit the LDS-resident FFT, else direct */
+  SPR_NCC_FFT = 1,    /* frequency-domain correlation, LDS-resident inverse 2-D FFT per channel */
+  SPR_NCC_DIRECT = 2  /* sliding-window correlation in LDS (any shape that fits LDS) */
+};
+
+typedef void* spr_stream_t;
+typedef struct spr_ncc_plan spr_ncc_plan;
+
+const char* spr_last_error(void);
+int spr_abi_version(void);
+
+/* ------------------------------------------------------------------ NCC scorer
+ *
+ * A plan fixes one (query shape, gallery shape) class: all queries are
+ * [C, q_h, q_w], all gallery items [C, g_h, g_w] (raw sizes, before the crop of
+ * `crop` pixels per edge that get_similarity applies, similarity.py:92-93; the
+ * reference uses crop = 2).  Ragged data sets are handled by the host code with one
+ * plan per shape class.
+ */
+typedef struct spr_ncc_shape {
+  int32_t channels;
+  int32_t q_h, q_w;
+  int32_t g_h, g_w;
+  int32_t crop;
+  int32_t dtype;   /* spr_dtype of the feature maps handed to spr_ncc_prepare_* */
+  int32_t method;  /* spr_ncc_method */
+} spr_ncc_shape;
+
+int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** plan_out);
+void spr_ncc_plan_destroy(spr_ncc_plan* plan);
+/* The method the plan resolved SPR_NCC_AUTO to (SPR_NCC_FFT / SPR_NCC_DIRECT). */
+int spr_ncc_plan_method(const spr_ncc_plan* plan);
+/* FFT grid the plan uses ({0,0} for the direct method): rows, cols. */
+int spr_ncc_plan_fft_size(const spr_ncc_plan* plan, int32_t* rows, int32_t* cols);
+
+/* Bytes of device memory the prepared form of n items needs. */
+size_t spr_ncc_query_bytes(const spr_ncc_plan* plan, int64_t n_queries);
+size_t spr_ncc_gallery_bytes(const spr_ncc_plan* plan, int64_t n_gallery);
+
+/* Prepare n items (device, [n,C,h,w]) into `prepared` (device, >= *_bytes(n)):
+ *  queries  (templates): crop, subtract the per-channel mean (similarity.py:48), scale by
+ *           1/sqrt(sum t0^2) (:67-68), and for the FFT method transform to the frequency
+ *           domain with the 'same'-mode centre shift (h//2, w//2) folded in.
+ *  gallery  (search images): crop, subtract the per-channel mean (:49), float64 window
+ *           sums -> 1/sqrt(var) map with var<=0 -> 0 (:57-65, :70), and for the FFT method
+ *           the forward transform of the zero-padded map. */
+int spr_ncc_prepare_queries(spr_ncc_plan* plan, const void* maps, int64_t n, void* prepared,
+                            spr_stream_t stream);
+int spr_ncc_prepare_gallery(spr_ncc_plan* plan, const void* maps, int64_t n, void* prepared,
+                            spr_stream_t stream);
+
+/* scores[q*ld + col0 + g] = max(prev, get_similarity(query q, gallery g)) as float32, where
+ * prev is 0 when accumulate_max == 0 (the reference's zero-initialised matrix,
+ * similarity.py:355) and the value already stored otherwise (max over rotation/scale
+ * variants, :364-367).  scores: device float32 [n_queries, ld]. */
+int spr_ncc_score(spr_ncc_plan* plan, const void* prepared_queries, int64_t n_queries,
+                  const void* prepared_gallery, int64_t n_gallery, float* scores, int64_t ld,
+                  int64_t col0, int accumulate_max, spr_stream_t stream);
+
+/* Debug / parity entry point (scripts/summed_feature_maps.py:1-6, similarity.py:100-104):
+ * per-channel NCC maps of ONE prepared query against ONE prepared gallery item, float32
+ * [C, g_h-2*crop, g_w-2*crop] (device). */
+int spr_ncc_maps(spr_ncc_plan* plan, const void* prepared_query, const void* prepared_gallery,
+                 float* maps_out, spr_stream_t stream);
+
+/* ------------------------------------------------------------------ ranking
+ * ranks[q] = 1-based position of gallery item match[q] in the descending order of row q
+ * (similarity.py:378-386): 1 + #{s_j > s_m} + #{j > m : s_j == s_m} (ties as a stable
+ * argsort + flip orders them).  A match index outside [0, n_gallery) gives rank 0 and the
+ * call returns SPR_OK; the host mirror turns that into the reference's IndexError.
+ * scores: device float32 [n_queries, ld]; match, ranks: device int32 [n_queries]. */
+int spr_rank_true_match(const float* scores, int64_t ld, int64_t n_queries, int64_t n_gallery,
+                        const int32_t* match, int32_t* ranks, spr_stream_t stream);
+
+/* Partial form for a gallery sharded over ranks: counts[q] = #{j in this shard : s_j > s_m}
+ * + #{j in this shard, global index > m : s_j == s_m}, given the true-match score of every
+ * query (match_scores, device float32 [n_queries]) and the global index of local column 0.
+ * Summing counts over shards and adding 1 gives the rank. */
+int spr_rank_count_greater(const float* scores, int64_t ld, int64_t n_queries, int64_t n_local,
+                           int64_t global_col0, const float* match_scores, const int32_t* match,
+                           int32_t* counts, spr_stream_t stream);
+
+/* ------------------------------------------------------------------ synthetic data
+ * Bench/test support: the device twin of shoeprint_image_retrieval_amd/synth.py (bit-identical
+ * float32 values).  out: device float32 [n, C, h, w]. */
+int spr_synth_gallery(float* out, int64_t first_item, int64_t n, int32_t channels, int32_t h,
+                      int32_t w, uint64_t seed, spr_stream_t stream);
+/* match: device int32 [n] = gallery index each query is derived from. */
+int spr_synth_queries(float* out, int64_t first_query, int64_t n, const int32_t* match,
+                      int32_t channels, int32_t h, int32_t w, uint64_t seed, int32_t max_shift,
+                      int32_t signal, int32_t noise, spr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHOEPRINT_MI355X_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of libshoeprint_mi355x.so (the C ABI in include/shoeprint_mi355x.h).
+
+The library is the product: there is no Python/CPU fallback.  ``load_library()`` raises if
+the in-tree shared object is missing (run ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C shoeprint-image-retrieval_amd/csrc``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "libshoeprint_mi355x.so")
+
+SPR_OK = 0
+F32, F16, BF16 = 0, 1, 2
+NCC_AUTO, NCC_FFT, NCC_DIRECT = 0, 1, 2
+METHOD_NAMES = {NCC_AUTO: "auto", NCC_FFT: "fft", NCC_DIRECT: "direct"}
+
+
+class NccShape(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32),
+        ("q_h", C.c_int32), ("q_w", C.c_int32),
+        ("g_h", C.c_int32), ("g_w", C.c_int32),
+        ("crop", C.c_int32),
+        ("dtype", C.c_int32),
+        ("method", C.c_int32),
+    ]
+
+
+class SprError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libshoeprint_mi355x error {code}: {message}")
+        self.code = code
+
+
+# name -> (restype, argtypes); every symbol include/shoeprint_mi355x.h declares
+_VP, _I64, _I32, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+SIGNATURES = {
+    "spr_last_error": (C.c_char_p, []),
+    "spr_abi_version": (C.c_int, []),
+    "spr_ncc_plan_create": (C.c_int, [C.POINTER(NccShape), C.POINTER(_VP)]),
+    "spr_ncc_plan_destroy": (None, [_VP]),
+    "spr_ncc_plan_method": (C.c_int, [_VP]),
+    "spr_ncc_plan_fft_size": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "spr_ncc_query_bytes": (_SZ, [_VP, _I64]),
+    "spr_ncc_gallery_bytes": (_SZ, [_VP, _I64]),
+    "spr_ncc_prepare_queries": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "spr_ncc_prepare_gallery": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "spr_ncc_score": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _VP, _I64, _I64, C.c_int, _VP]),
+    "spr_ncc_maps": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "spr_rank_true_match": (C.c_int, [_VP, _I64, _I64, _I64, _VP, _VP, _VP]),
+    "spr_rank_count_greater": (C.c_int, [_VP, _I64, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
+    "spr_synth_gallery": (C.c_int, [_VP, _I64, _I64, _I32, _I32, _I32, C.c_uint64, _VP]),
+    "spr_synth_queries": (C.c_int, [_VP, _I64, _I64, _VP, _I32, _I32, _I32, C.c_uint64, _I32, _I32, _I32, _VP]),
+}
+
+
+class Library:
+    """The loaded shared object with typed entry points; ``check`` turns status codes into SprError."""
+
+    def __init__(self, path: str | None = None):
+        self.path = path or DEFAULT_PATH
+        if not os.path.exists(self.path):
+            raise RuntimeError(
+                f"{self.path} not found: the HIP library is the product and has no fallback. "
+                "Build it with `make -C shoeprint-image-retrieval_amd/csrc` (or __graft_entry__.build())."
+            )
+        self.cdll = C.CDLL(self.path)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the ABI is incomplete
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+        if self.spr_abi_version() != 1:
+            raise RuntimeError(f"{self.path}: ABI version {self.spr_abi_version()} != 1")
+
+    def check(self, code: int) -> None:
+        if code != SPR_OK:
+            raise SprError(code, (self.spr_last_error() or b"").decode("utf-8", "replace"))
+
+
+_default: Library | None = None
+
+
+def load_library(path: str | None = None) -> Library:
+    """The process-wide library (in-tree build).  An explicit ``path`` loads another build
+    (the tests use this for the CPU-emulation twin); it never replaces the default."""
+    global _default
+    if path is not None:
+        return Library(path)
+    if _default is None:
+        _default = Library()
+    return _default

@@ -1,0 +1,208 @@
+// C ABI entry points of libshoeprint_mi355x.so (include/shoeprint_mi355x.h) for the NCC scorer.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+#include <vector>
+
+#include "spr_common.h"
+
+namespace spr {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SPR_ERR_HIP;
+  }
+  return SPR_OK;
+}
+
+size_t prepared_query_item_bytes(const NccGeom& g, int method) {
+  size_t b;
+  if (method == SPR_NCC_FFT)
+    b = sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan;
+  else
+    b = sizeof(float) * static_cast<size_t>(g.channels) * g.th * g.tw;
+  return align_up(b, 256);
+}
+
+size_t prepared_gallery_item_bytes(const NccGeom& g, int method) {
+  size_t b;
+  if (method == SPR_NCC_FFT)
+    b = static_cast<size_t>(g.channels) * (sizeof(cf) * g.spec_per_chan + sizeof(float) * g.inv_per_chan);
+  else
+    b = sizeof(float) * static_cast<size_t>(g.channels) * g.ih * g.iw * 2;
+  return align_up(b, 256);
+}
+
+}  // namespace spr
+
+struct spr_ncc_plan {
+  spr::NccGeom geom;
+  int method;              // resolved: SPR_NCC_FFT or SPR_NCC_DIRECT
+  spr::cf* tw_h = nullptr;  // device: exp(-2*pi*i*k/nh), k < nh
+  spr::cf* tw_w = nullptr;  // device: exp(-2*pi*i*k/nw), k < nw
+};
+
+using namespace spr;
+
+static int make_twiddles(int n, cf** out) {
+  std::vector<cf> host(static_cast<size_t>(n));
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int k = 0; k < n; ++k) {
+    const double a = -two_pi * static_cast<double>(k) / static_cast<double>(n);
+    host[k].x = static_cast<float>(std::cos(a));
+    host[k].y = static_cast<float>(std::sin(a));
+  }
+  // exact values on the axes (cos/sin of multiples of pi/2 are not exact in floating point)
+  if (n % 4 == 0) {
+    host[n / 4] = cf{0.0f, -1.0f};
+    host[n / 2] = cf{-1.0f, 0.0f};
+    host[3 * n / 4] = cf{0.0f, 1.0f};
+  } else if (n % 2 == 0) {
+    host[n / 2] = cf{-1.0f, 0.0f};
+  }
+  void* dev = nullptr;
+  if (hipMalloc(&dev, sizeof(cf) * n) != hipSuccess) { set_error("hipMalloc(twiddles) failed"); return SPR_ERR_HIP; }
+  if (hipMemcpy(dev, host.data(), sizeof(cf) * n, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(dev);
+    set_error("hipMemcpy(twiddles) failed");
+    return SPR_ERR_HIP;
+  }
+  *out = static_cast<cf*>(dev);
+  return SPR_OK;
+}
+
+extern "C" const char* spr_last_error(void) { return g_error; }
+extern "C" int spr_abi_version(void) { return SPR_ABI_VERSION; }
+
+extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** plan_out) {
+  if (!shape || !plan_out) { set_error("spr_ncc_plan_create: null pointer"); return SPR_ERR_ARG; }
+  *plan_out = nullptr;
+  if (shape->channels <= 0 || shape->crop < 0) { set_error("spr_ncc_plan_create: bad channels/crop"); return SPR_ERR_ARG; }
+  if (shape->dtype != SPR_F32 && shape->dtype != SPR_F16 && shape->dtype != SPR_BF16) {
+    set_error("spr_ncc_plan_create: unknown dtype %d", shape->dtype);
+    return SPR_ERR_ARG;
+  }
+  if (shape->method != SPR_NCC_AUTO && shape->method != SPR_NCC_FFT && shape->method != SPR_NCC_DIRECT) {
+    set_error("spr_ncc_plan_create: unknown method %d", shape->method);
+    return SPR_ERR_ARG;
+  }
+  NccGeom g{};
+  g.channels = shape->channels;
+  g.q_h = shape->q_h; g.q_w = shape->q_w; g.g_h = shape->g_h; g.g_w = shape->g_w;
+  g.crop = shape->crop;
+  g.dtype = shape->dtype;
+  g.th = g.q_h - 2 * g.crop; g.tw = g.q_w - 2 * g.crop;
+  g.ih = g.g_h - 2 * g.crop; g.iw = g.g_w - 2 * g.crop;
+  if (g.th < 1 || g.tw < 1 || g.ih < 1 || g.iw < 1) {
+    set_error("spr_ncc_plan_create: maps %dx%d / %dx%d vanish under a crop of %d", g.q_h, g.q_w, g.g_h, g.g_w, g.crop);
+    return SPR_ERR_SHAPE;
+  }
+  int method = 0;
+  NccGeom gf = g, gd = g;
+  const bool fft_ok = fft_geometry(gf), direct_ok = direct_geometry(gd);
+  if (shape->method == SPR_NCC_FFT) {
+    if (!fft_ok) { set_error("FFT method: no instantiated LDS-resident grid fits query %dx%d vs gallery %dx%d", g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
+    method = SPR_NCC_FFT;
+  } else if (shape->method == SPR_NCC_DIRECT) {
+    if (!direct_ok) { set_error("direct method: maps %dx%d vs %dx%d do not fit LDS", g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
+    method = SPR_NCC_DIRECT;
+  } else if (fft_ok) {
+    method = SPR_NCC_FFT;
+  } else if (direct_ok) {
+    method = SPR_NCC_DIRECT;
+  } else {
+    set_error("no NCC kernel fits query %dx%d vs gallery %dx%d (cropped) in LDS", g.th, g.tw, g.ih, g.iw);
+    return SPR_ERR_UNSUPPORTED;
+  }
+  spr_ncc_plan* p = new (std::nothrow) spr_ncc_plan();
+  if (!p) { set_error("out of host memory"); return SPR_ERR_ARG; }
+  p->method = method;
+  p->geom = method == SPR_NCC_FFT ? gf : gd;
+  if (method == SPR_NCC_FFT) {
+    int rc = make_twiddles(p->geom.nh, &p->tw_h);
+    if (rc == SPR_OK) rc = make_twiddles(p->geom.nw, &p->tw_w);
+    if (rc != SPR_OK) { spr_ncc_plan_destroy(p); return rc; }
+  }
+  *plan_out = p;
+  return SPR_OK;
+}
+
+extern "C" void spr_ncc_plan_destroy(spr_ncc_plan* plan) {
+  if (!plan) return;
+  if (plan->tw_h) (void)hipFree(plan->tw_h);
+  if (plan->tw_w) (void)hipFree(plan->tw_w);
+  delete plan;
+}
+
+extern "C" int spr_ncc_plan_method(const spr_ncc_plan* plan) { return plan ? plan->method : SPR_ERR_ARG; }
+
+extern "C" int spr_ncc_plan_fft_size(const spr_ncc_plan* plan, int32_t* rows, int32_t* cols) {
+  if (!plan || !rows || !cols) { set_error("spr_ncc_plan_fft_size: null pointer"); return SPR_ERR_ARG; }
+  *rows = plan->method == SPR_NCC_FFT ? plan->geom.nh : 0;
+  *cols = plan->method == SPR_NCC_FFT ? plan->geom.nw : 0;
+  return SPR_OK;
+}
+
+extern "C" size_t spr_ncc_query_bytes(const spr_ncc_plan* plan, int64_t n) {
+  if (!plan || n < 0) return 0;
+  return prepared_query_item_bytes(plan->geom, plan->method) * static_cast<size_t>(n);
+}
+extern "C" size_t spr_ncc_gallery_bytes(const spr_ncc_plan* plan, int64_t n) {
+  if (!plan || n < 0) return 0;
+  return prepared_gallery_item_bytes(plan->geom, plan->method) * static_cast<size_t>(n);
+}
+
+static int prepare(spr_ncc_plan* plan, bool is_query, const void* maps, int64_t n, void* prepared, spr_stream_t stream,
+                   const char* who) {
+  if (!plan) { set_error("%s: null plan", who); return SPR_ERR_ARG; }
+  if (n < 0 || n > 65535) { set_error("%s: n = %lld outside [0, 65535] (call in chunks)", who, static_cast<long long>(n)); return SPR_ERR_ARG; }
+  if (n == 0) return SPR_OK;
+  if (!maps || !prepared) { set_error("%s: null pointer", who); return SPR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan->method == SPR_NCC_FFT)
+    return launch_prep_fft(plan->geom, is_query, maps, n, prepared, plan->tw_h, plan->tw_w, s);
+  return launch_prep_direct(plan->geom, is_query, maps, n, prepared, s);
+}
+
+extern "C" int spr_ncc_prepare_queries(spr_ncc_plan* plan, const void* maps, int64_t n, void* prepared,
+                                       spr_stream_t stream) {
+  return prepare(plan, true, maps, n, prepared, stream, "spr_ncc_prepare_queries");
+}
+extern "C" int spr_ncc_prepare_gallery(spr_ncc_plan* plan, const void* maps, int64_t n, void* prepared,
+                                       spr_stream_t stream) {
+  return prepare(plan, false, maps, n, prepared, stream, "spr_ncc_prepare_gallery");
+}
+
+extern "C" int spr_ncc_score(spr_ncc_plan* plan, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+                             int64_t ld, int64_t col0, int accumulate_max, spr_stream_t stream) {
+  if (!plan) { set_error("spr_ncc_score: null plan"); return SPR_ERR_ARG; }
+  if (nq < 0 || ng < 0 || col0 < 0 || ld < col0 + ng) { set_error("spr_ncc_score: bad sizes"); return SPR_ERR_ARG; }
+  if (nq == 0 || ng == 0) return SPR_OK;
+  if (!pq || !pg || !scores) { set_error("spr_ncc_score: null pointer"); return SPR_ERR_ARG; }
+  if (nq > 65535 || ng > (1 << 24)) { set_error("spr_ncc_score: too many items in one call (chunk the gallery)"); return SPR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan->method == SPR_NCC_FFT)
+    return launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
+                           plan->tw_w, s);
+  return launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
+}
+
+extern "C" int spr_ncc_maps(spr_ncc_plan* plan, const void* pq, const void* pg, float* maps_out, spr_stream_t stream) {
+  if (!plan || !pq || !pg || !maps_out) { set_error("spr_ncc_maps: null pointer"); return SPR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan->method == SPR_NCC_FFT)
+    return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w, s);
+  return launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
+}

@@ -1,0 +1,206 @@
+// In-register DFTs and the two-stage "group FFT" used by the NCC kernels.
+//
+// A transform of length N = E * TG is computed by a group of TG consecutive lanes of one wave,
+// each lane holding E complex values in registers:
+//
+//   on entry   x[m]  = data[t + TG*m]                 (t = lane in group, m = 0..E-1)
+//   stage 1    length-E DFT over m in registers      -> U_t[p], p = 0..E-1
+//   twiddle    U_t[p] *= w_N^(±t*p)
+//   exchange   through LDS: lane t receives U_tt[t + TG*pp] for tt = 0..TG-1, pp = 0..E/TG-1
+//   stage 2    E/TG length-TG DFTs over tt in registers
+//   on exit    x[m'] = result[t + TG*m'],  m' = pp + (E/TG)*s
+//
+// i.e. input and output use the same lane/register <-> index map, so a forward transform's
+// output can be stored as it lies and loaded as the inverse transform's input.
+//
+// DIR = -1: forward, kernel exp(-2*pi*i*k*n/N).  DIR = +1: inverse (unnormalised).
+#pragma once
+#include "spr_common.h"
+
+namespace spr {
+
+__device__ __forceinline__ cf cmake(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cconj(cf a) { return cmake(a.x, -a.y); }
+// multiply by +i / -i
+__device__ __forceinline__ cf cmul_i(cf a) { return cmake(-a.y, a.x); }
+__device__ __forceinline__ cf cmul_mi(cf a) { return cmake(a.y, -a.x); }
+
+// cos / sin of 2*pi*k/48, k = 0..47 (covers the 16th and 24th roots of unity), rounded from
+// double precision.
+__device__ constexpr float kCos48[48] = {
+    1.0f, 0.99144486137381038f, 0.96592582628906831f, 0.92387953251128674f, 0.86602540378443860f,
+    0.79335334029123517f, 0.70710678118654757f, 0.60876142900872066f, 0.5f, 0.38268343236508984f,
+    0.25881904510252074f, 0.13052619222005171f, 0.0f, -0.13052619222005160f, -0.25881904510252063f,
+    -0.38268343236508973f, -0.5f, -0.60876142900872054f, -0.70710678118654746f, -0.79335334029123517f,
+    -0.86602540378443871f, -0.92387953251128674f, -0.96592582628906831f, -0.99144486137381038f, -1.0f,
+    -0.99144486137381049f, -0.96592582628906842f, -0.92387953251128685f, -0.86602540378443882f,
+    -0.79335334029123528f, -0.70710678118654768f, -0.60876142900872088f, -0.5f, -0.38268343236509034f,
+    -0.25881904510252152f, -0.13052619222005160f, 0.0f, 0.13052619222005127f, 0.25881904510252035f,
+    0.38268343236509000f, 0.5f, 0.60876142900872066f, 0.70710678118654735f, 0.79335334029123494f,
+    0.86602540378443837f, 0.92387953251128652f, 0.96592582628906820f, 0.99144486137381038f};
+__device__ constexpr float kSin48[48] = {
+    0.0f, 0.13052619222005157f, 0.25881904510252074f, 0.38268343236508978f, 0.5f, 0.60876142900872066f,
+    0.70710678118654746f, 0.79335334029123517f, 0.86602540378443860f, 0.92387953251128674f,
+    0.96592582628906831f, 0.99144486137381038f, 1.0f, 0.99144486137381038f, 0.96592582628906831f,
+    0.92387953251128674f, 0.86602540378443871f, 0.79335334029123528f, 0.70710678118654757f,
+    0.60876142900872066f, 0.5f, 0.38268343236508989f, 0.25881904510252102f, 0.13052619222005157f, 0.0f,
+    -0.13052619222005132f, -0.25881904510252079f, -0.38268343236508967f, -0.5f, -0.60876142900872054f,
+    -0.70710678118654746f, -0.79335334029123494f, -0.86602540378443849f, -0.92387953251128652f,
+    -0.96592582628906809f, -0.99144486137381038f, -1.0f, -0.99144486137381049f, -0.96592582628906842f,
+    -0.92387953251128663f, -0.86602540378443882f, -0.79335334029123517f, -0.70710678118654779f,
+    -0.60876142900872088f, -0.5f, -0.38268343236509039f, -0.25881904510252157f, -0.13052619222005168f};
+
+// x *= exp(DIR * 2*pi*i * K / N) with K, N compile-time (N divides 48); trivial factors cost nothing.
+template <int N, int K, int DIR>
+__device__ __forceinline__ cf rot(cf a) {
+  constexpr int k = ((K % N) + N) % N;
+  if constexpr (k == 0) {
+    return a;
+  } else if constexpr (2 * k == N) {
+    return cmake(-a.x, -a.y);
+  } else if constexpr (4 * k == N) {
+    return DIR > 0 ? cmul_i(a) : cmul_mi(a);
+  } else if constexpr (4 * k == 3 * N) {
+    return DIR > 0 ? cmul_mi(a) : cmul_i(a);
+  } else {
+    constexpr float c = kCos48[k * (48 / N)];
+    constexpr float s = DIR > 0 ? kSin48[k * (48 / N)] : -kSin48[k * (48 / N)];
+    return cmake(a.x * c - a.y * s, a.x * s + a.y * c);
+  }
+}
+
+template <int N, int DIR>
+struct Dft;
+
+template <int DIR>
+struct Dft<1, DIR> {
+  static __device__ __forceinline__ void run(cf (&)[1]) {}
+};
+template <int DIR>
+struct Dft<2, DIR> {
+  static __device__ __forceinline__ void run(cf (&x)[2]) {
+    const cf a = x[0], b = x[1];
+    x[0] = cadd(a, b);
+    x[1] = csub(a, b);
+  }
+};
+template <int DIR>
+struct Dft<3, DIR> {
+  static __device__ __forceinline__ void run(cf (&x)[3]) {
+    // X0 = a+b+c; X1 = a + w b + w^2 c; X2 = a + w^2 b + w c, w = exp(DIR*2pi*i/3)
+    const cf a = x[0], s = cadd(x[1], x[2]), d = csub(x[1], x[2]);
+    constexpr float h = 0.86602540378443860f;  // sin(2*pi/3)
+    const cf m = cmake(a.x - 0.5f * s.x, a.y - 0.5f * s.y);
+    const cf j = DIR > 0 ? cmake(-h * d.y, h * d.x) : cmake(h * d.y, -h * d.x);  // ±i*h*d
+    x[0] = cadd(a, s);
+    x[1] = cadd(m, j);
+    x[2] = csub(m, j);
+  }
+};
+
+// Decimation-in-time step: N = 2 * (N/2), even/odd split, natural-order output.
+template <int N, int DIR, int K>
+struct Combine2 {
+  static __device__ __forceinline__ void run(cf (&x)[N], const cf (&e)[N / 2], const cf (&o)[N / 2]) {
+    const cf t = rot<N, K, DIR>(o[K]);
+    x[K] = cadd(e[K], t);
+    x[K + N / 2] = csub(e[K], t);
+    if constexpr (K + 1 < N / 2) Combine2<N, DIR, K + 1>::run(x, e, o);
+  }
+};
+
+template <int N, int DIR>
+struct Dft {
+  static __device__ __forceinline__ void run(cf (&x)[N]) {
+    if constexpr (N % 2 == 0) {
+      cf e[N / 2], o[N / 2];
+#pragma unroll
+      for (int k = 0; k < N / 2; ++k) {
+        e[k] = x[2 * k];
+        o[k] = x[2 * k + 1];
+      }
+      Dft<N / 2, DIR>::run(e);
+      Dft<N / 2, DIR>::run(o);
+      Combine2<N, DIR, 0>::run(x, e, o);
+    } else {
+      static_assert(N % 3 == 0, "radices 2 and 3 only");
+      // N = 3 * (N/3): three interleaved sub-transforms, then length-3 butterflies
+      cf a[N / 3], b[N / 3], c[N / 3];
+#pragma unroll
+      for (int k = 0; k < N / 3; ++k) {
+        a[k] = x[3 * k];
+        b[k] = x[3 * k + 1];
+        c[k] = x[3 * k + 2];
+      }
+      Dft<N / 3, DIR>::run(a);
+      Dft<N / 3, DIR>::run(b);
+      Dft<N / 3, DIR>::run(c);
+      Combine3<0>(x, a, b, c);
+    }
+  }
+  template <int K>
+  static __device__ __forceinline__ void Combine3(cf (&x)[N], const cf (&a)[N / 3], const cf (&b)[N / 3],
+                                                   const cf (&c)[N / 3]) {
+    cf t[3] = {a[K], rot<N, K, DIR>(b[K]), rot<N, 2 * K, DIR>(c[K])};
+    Dft<3, DIR>::run(t);
+    x[K] = t[0];
+    x[K + N / 3] = t[1];
+    x[K + 2 * N / 3] = t[2];
+    if constexpr (K + 1 < N / 3) Combine3<K + 1>(x, a, b, c);
+  }
+};
+
+// Stride (in complex elements) between the p-rows of a group's exchange image, and the size of
+// one group's image.  The +1 keeps the strided reads of stage 2 off a single bank.
+template <int E, int TG>
+struct GroupFftLds {
+  static constexpr int kRow = TG + 1;
+  static constexpr int kGroupElems = E * kRow;
+  // elements for a whole workgroup of kThreads lanes
+  static constexpr int kBlockElems = (kThreads / TG) * kGroupElems;
+};
+
+// Per-lane twiddles w_N^(DIR*t*p), p = 0..E-1, from the forward table tw[k] = exp(-2*pi*i*k/N).
+template <int E, int TG, int DIR>
+__device__ __forceinline__ void load_twiddles(cf (&twr)[E], const cf* __restrict__ tw, int t) {
+#pragma unroll
+  for (int p = 0; p < E; ++p) {
+    const cf w = tw[t * p];
+    twr[p] = DIR > 0 ? cconj(w) : w;
+  }
+}
+
+// The transform described at the top of this file.  `xbuf` is this group's exchange image
+// (GroupFftLds<E,TG>::kGroupElems complex values of LDS); every lane of the wave must call this
+// function together.  The image may be reused as soon as the function returns.
+template <int E, int TG, int DIR>
+__device__ __forceinline__ void group_fft(cf (&x)[E], int t, const cf (&twr)[E], cf* xbuf) {
+  constexpr int PP = E / TG;
+  static_assert(E % TG == 0, "E must be a multiple of TG");
+  constexpr int kRow = GroupFftLds<E, TG>::kRow;
+  Dft<E, DIR>::run(x);
+#pragma unroll
+  for (int p = 0; p < E; ++p) {
+    const cf v = p == 0 ? x[0] : cmul(x[p], twr[p]);
+    xbuf[p * kRow + t] = v;
+  }
+  wave_sync();
+  cf y[PP][TG];
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[(t + TG * pp) * kRow + tt];
+  }
+  wave_sync();
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+    Dft<TG, DIR>::run(y[pp]);
+#pragma unroll
+    for (int s = 0; s < TG; ++s) x[pp + PP * s] = y[pp][s];
+  }
+}
+
+}  // namespace spr

@@ -1,0 +1,503 @@
+// FFT-method NCC scorer (the fast path).
+//
+// Correlation theorem:  num = IFFT2( FFT2(I0z) . conj(FFT2(t^)) )  on an nh x nw grid large enough
+// that the 'same'-mode lags are free of circular aliasing (nh >= ih + max(th/2, th-1-th/2), same
+// for nw).  The reference does exactly this through scipy's fftconvolve for every pair and channel
+// (similarity.py:55: 2 forward + 1 inverse FFT per call, 3 calls per channel); here
+//
+//   prep kernels (once per item and channel)
+//     gallery: centre -> float64 window sums -> 1/sigma map; forward 2-D FFT of the zero-padded map
+//     query:   centre -> scale by 1/sqrt(sum t0^2) -> forward 2-D FFT, conjugated, with the 'same'
+//              centre shift (th/2, tw/2) and the 1/(nh*nw) inverse-FFT factor folded in
+//   pair kernel (one workgroup per (query, gallery) pair, loop over channels)
+//     spectrum product -> inverse column FFTs (only the rows that cover ih are kept, in LDS)
+//     -> inverse row FFTs, two rows per complex transform (rows are real) -> multiply by the
+//     1/sigma map -> accumulate the channel sum in registers -> final wave/LDS max-reduction.
+//
+// All FFTs are LDS/register resident (fft_core.h): the pair kernel's only HBM/L2 traffic is the two
+// half-spectra and the 1/sigma map of the current channel, laid out in exactly the lane/register order
+// the kernel consumes (fully coalesced 8/16-byte loads).
+//
+// Half-spectrum bookkeeping (rows are real => X[k1][nw-k2] = conj(X[-k1][k2])):
+//   columns k2 = 0 .. nw/2 are stored; the pair kernel runs nw/2 column transforms, the first of
+//   which carries columns 0 and nw/2 packed as  P0 + i*Pn  (both give real column results).
+#include "fft_core.h"
+#include "ncc_prep_common.h"
+
+namespace spr {
+namespace {
+
+template <int EH_, int TGH_, int EW_, int TGW_>
+struct Cfg {
+  static constexpr int EH = EH_, TGH = TGH_, EW = EW_, TGW = TGW_;
+  static constexpr int NH = EH * TGH, NW = EW * TGW;
+  static constexpr int CPR = kThreads / TGH;  // columns per column-pass round
+  static constexpr int PPR = kThreads / TGW;  // row pairs per row-pass round
+  static constexpr int PPW = EW / TGW;
+  static constexpr int XBUF = GroupFftLds<EH, TGH>::kBlockElems > GroupFftLds<EW, TGW>::kBlockElems
+                                  ? GroupFftLds<EH, TGH>::kBlockElems
+                                  : GroupFftLds<EW, TGW>::kBlockElems;
+};
+
+// ============================================================================================
+// Forward (prep) kernel.  grid = (channels, n_items)
+// ============================================================================================
+template <class C>
+__global__ void __launch_bounds__(kThreads)
+prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
+                size_t item_bytes, const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned x0_off,
+                unsigned f_off, unsigned xbuf_off, int f_stride) {
+  unsigned char* lds = dyn_lds();
+  double* red = reinterpret_cast<double*>(lds);
+  float* x0 = reinterpret_cast<float*>(lds + x0_off);
+  double* sat = reinterpret_cast<double*>(lds + f_off);  // dead before F is written
+  cf* F = reinterpret_cast<cf*>(lds + f_off);
+  cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
+  const int tid = static_cast<int>(threadIdx.x);
+  const int c = static_cast<int>(blockIdx.x);
+  const size_t item = blockIdx.y;
+  const int h = is_query ? g.th : g.ih, w = is_query ? g.tw : g.iw;
+  const int raw_h = is_query ? g.q_h : g.g_h, raw_w = is_query ? g.q_w : g.g_w;
+
+  unsigned char* item_base = prepared + item * item_bytes;
+  cf* spec = reinterpret_cast<cf*>(item_base) + static_cast<size_t>(c) * g.spec_per_chan;
+
+  load_centred(maps, (item * g.channels + c) * static_cast<size_t>(raw_h) * raw_w, raw_w, g.crop, h, w, g.dtype, x0,
+               red);
+  float scale = 1.0f;
+  if (is_query) {
+    scale = template_scale(x0, h * w, red) * (1.0f / (static_cast<float>(C::NH) * static_cast<float>(C::NW)));
+  } else {
+    // 1/sigma map in the pair kernel's register order; slots no pixel maps to stay 0.
+    float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan) +
+                 static_cast<size_t>(c) * g.inv_per_chan;
+    for (int i = tid; i < g.inv_per_chan; i += kThreads) inv[i] = 0.0f;
+    __syncthreads();
+    const int nv = C::PPW * g.keep_w * 2;
+    inv_sigma_map(x0, h, w, g.th, g.tw, sat, [&](int i, float v) {
+      const int n1 = i / w, n2 = i - n1 * w;
+      const int pr = n1 >> 1, ab = n1 & 1;
+      const int rr = pr / C::PPR, giw = pr - rr * C::PPR;
+      const int p = n2 % C::EW, s = n2 / C::EW;
+      const int pp = p / C::TGW, t = p - pp * C::TGW;
+      const int e2 = (pp * g.keep_w + s) * 2 + ab;
+      const int lane = giw * C::TGW + t;
+      inv[((rr * (nv / 4) + (e2 >> 2)) * kThreads + lane) * 4 + (e2 & 3)] = v;
+    });
+  }
+
+  // ---- row pass: two real rows per complex transform of length NW -------------------------------
+  {
+    const int giw = tid / C::TGW, t = tid - giw * C::TGW;
+    cf twr[C::EW];
+    load_twiddles<C::EW, C::TGW, -1>(twr, tw_w, t);
+    cf* gbuf = xbuf + giw * GroupFftLds<C::EW, C::TGW>::kGroupElems;
+    const int pairs = (h + 1) / 2;
+    const int rounds = ceil_div(pairs, C::PPR);
+    for (int rr = 0; rr < rounds; ++rr) {
+      const int pr = rr * C::PPR + giw;
+      const int ra = 2 * pr, rb = ra + 1;
+      cf x[C::EW];
+#pragma unroll
+      for (int m = 0; m < C::EW; ++m) {
+        const int n2 = t + C::TGW * m;
+        const bool in = n2 < w;
+        x[m].x = (in && ra < h) ? x0[ra * w + n2] * scale : 0.0f;
+        x[m].y = (in && rb < h) ? x0[rb * w + n2] * scale : 0.0f;
+      }
+      group_fft<C::EW, C::TGW, -1>(x, t, twr, gbuf);
+      // publish Z[k] for the group, then split the two real rows:  Xa = (Z[k] + conj Z[-k])/2,
+      // Xb = (Z[k] - conj Z[-k])/(2i)
+#pragma unroll
+      for (int m = 0; m < C::EW; ++m) gbuf[t + C::TGW * m] = x[m];
+      wave_sync();
+      if (pr < pairs) {
+#pragma unroll
+        for (int m = 0; m < C::EW; ++m) {
+          const int k = t + C::TGW * m;
+          if (k <= C::NW / 2) {
+            const cf zk = gbuf[k];
+            const cf zm = gbuf[(C::NW - k) & (C::NW - 1)];
+            F[ra * f_stride + k] = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            F[rb * f_stride + k] = cmake(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+          }
+        }
+      }
+      wave_sync();
+    }
+  }
+  __syncthreads();
+
+  // ---- column pass: nw/2 + 1 columns of length NH ----------------------------------------------
+  {
+    const int gi = tid / C::TGH, t = tid - gi * C::TGH;
+    cf twr[C::EH];
+    load_twiddles<C::EH, C::TGH, -1>(twr, tw_h, t);
+    cf* gbuf = xbuf + gi * GroupFftLds<C::EH, C::TGH>::kGroupElems;
+    const int rows_f = 2 * ((h + 1) / 2);
+    const int cy = g.th / 2, cx = g.tw / 2;
+    for (int rc = 0; rc <= g.rounds_c; ++rc) {
+      const bool nyq = rc == g.rounds_c;
+      const int j = nyq ? C::NW / 2 : rc * C::CPR + gi;
+      const bool active = nyq ? gi == 0 : j < C::NW / 2;
+      cf x[C::EH];
+#pragma unroll
+      for (int m = 0; m < C::EH; ++m) {
+        const int n1 = t + C::TGH * m;
+        x[m] = (active && n1 < rows_f) ? F[n1 * f_stride + j] : cmake(0.0f, 0.0f);
+      }
+      group_fft<C::EH, C::TGH, -1>(x, t, twr, gbuf);
+      if (active) {
+        cf wx = cmake(1.0f, 0.0f);
+        if (is_query) wx = tw_w[(cx * j) & (C::NW - 1)];
+#pragma unroll
+        for (int m = 0; m < C::EH; ++m) {
+          cf v = x[m];
+          if (is_query) {
+            const int k1 = t + C::TGH * m;
+            const cf wy = tw_h[(cy * k1) & (C::NH - 1)];
+            v = cmul(cmul(cconj(v), wy), wx);  // conj(A) * w^(cy k1) * w^(cx k2): centre shift folded in
+          }
+          if (nyq)
+            spec[static_cast<size_t>(g.rounds_c) * C::EH * kThreads + m * C::TGH + t] = v;
+          else
+            spec[(static_cast<size_t>(rc) * C::EH + m) * kThreads + tid] = v;
+        }
+      }
+    }
+  }
+}
+
+// ============================================================================================
+// Pair kernel.  One workgroup per (query, gallery) pair; 1-D grid tiled so that the workgroups
+// resident together share a small set of query and gallery spectra (L2 / Infinity-Cache reuse).
+// ============================================================================================
+constexpr int kTileQ = 16, kTileG = 16;
+
+template <class C, int RR, int KW>
+__global__ void __launch_bounds__(kThreads)
+pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
+                const unsigned char* __restrict__ pg, size_t g_item_bytes, int nq, int ng, float* __restrict__ scores,
+                long long ld, long long col0, int accumulate, float* __restrict__ maps_out,
+                const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off) {
+  // ---- which pair ------------------------------------------------------------------------------
+  const int tiles_g = ceil_div(ng, kTileG);
+  const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
+  const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
+  const int tq = tile / tiles_g, tg = tile - tq * tiles_g;
+  const int qi = tq * kTileQ + within / kTileG;
+  const int gi_item = tg * kTileG + within % kTileG;
+  if (qi >= nq || gi_item >= ng) return;  // uniform per workgroup
+
+  unsigned char* lds = dyn_lds();
+  float* red = reinterpret_cast<float*>(lds);
+  cf* R = reinterpret_cast<cf*>(lds + r_off);
+  cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
+  const int tid = static_cast<int>(threadIdx.x);
+  constexpr int NV = C::PPW * KW * 2;  // accumulators per lane and row round
+
+  const cf* qspec = reinterpret_cast<const cf*>(pq + static_cast<size_t>(qi) * q_item_bytes);
+  const cf* gspec = reinterpret_cast<const cf*>(pg + static_cast<size_t>(gi_item) * g_item_bytes);
+  const float* ginv = reinterpret_cast<const float*>(pg + static_cast<size_t>(gi_item) * g_item_bytes +
+                                                     sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan);
+
+  const int gc = tid / C::TGH, tc = tid - gc * C::TGH;  // column-pass group / lane in group
+  const int gr = tid / C::TGW, tr = tid - gr * C::TGW;  // row-pass group / lane in group
+  cf twc[C::EH], twr[C::EW];
+  load_twiddles<C::EH, C::TGH, +1>(twc, tw_h, tc);
+  load_twiddles<C::EW, C::TGW, +1>(twr, tw_w, tr);
+  cf* cbuf = xbuf + gc * GroupFftLds<C::EH, C::TGH>::kGroupElems;
+  cf* rbuf = xbuf + gr * GroupFftLds<C::EW, C::TGW>::kGroupElems;
+
+  float acc[RR][NV];
+#pragma unroll
+  for (int r = 0; r < RR; ++r)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
+
+  const int pairs = g.r_rows / 2;
+  const size_t nyq_off = static_cast<size_t>(g.rounds_c) * C::EH * kThreads;
+
+  for (int c = 0; c < g.channels; ++c) {
+    const cf* qs = qspec + static_cast<size_t>(c) * g.spec_per_chan;
+    const cf* gs = gspec + static_cast<size_t>(c) * g.spec_per_chan;
+    // ---- column pass: product spectrum -> inverse transforms along k1 -> R (rows < r_rows) -------
+    for (int rc = 0; rc < g.rounds_c; ++rc) {
+      const int j = rc * C::CPR + gc;
+      const bool active = j < C::NW / 2;
+      cf z[C::EH];
+#pragma unroll
+      for (int m = 0; m < C::EH; ++m) {
+        const size_t idx = (static_cast<size_t>(rc) * C::EH + m) * kThreads + tid;
+        z[m] = active ? cmul(gs[idx], qs[idx]) : cmake(0.0f, 0.0f);
+      }
+      if (j == 0) {  // pack column nw/2 into the imaginary part of column 0
+#pragma unroll
+        for (int m = 0; m < C::EH; ++m) {
+          const size_t idx = nyq_off + m * C::TGH + tc;
+          const cf zn = cmul(gs[idx], qs[idx]);
+          z[m] = cmake(z[m].x - zn.y, z[m].y + zn.x);
+        }
+      }
+      group_fft<C::EH, C::TGH, +1>(z, tc, twc, cbuf);
+      if (active) {
+#pragma unroll
+        for (int m = 0; m < C::EH; ++m) {
+          const int n1 = tc + C::TGH * m;
+          if (n1 < g.r_rows) R[n1 * g.r_stride + j] = z[m];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- row pass: two real rows per inverse transform along k2 -> * 1/sigma -> accumulate --------
+    const float4* inv4 = reinterpret_cast<const float4*>(ginv + static_cast<size_t>(c) * g.inv_per_chan);
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      if (rr >= g.rounds_r) break;  // uniform: RR is the variant's compile-time maximum
+      int pr = rr * C::PPR + gr;
+      if (pr >= pairs) pr = pairs - 1;  // duplicate work on surplus lanes; their 1/sigma slots are 0
+      const cf* Ra = R + (2 * pr) * g.r_stride;
+      const cf* Rb = Ra + g.r_stride;
+      cf wv[C::EW];
+#pragma unroll
+      for (int m = 0; m < C::EW; ++m) {
+        const int k = tr + C::TGW * m;
+        const bool upper = k > C::NW / 2;
+        const int kk = upper ? C::NW - k : k;
+        const int idx = kk == C::NW / 2 ? 0 : kk;
+        const cf a = Ra[idx], b = Rb[idx];
+        const float ay = upper ? -a.y : a.y, by = upper ? -b.y : b.y;
+        cf v = cmake(a.x - by, ay + b.x);        // Ya[k] + i*Yb[k]  (conjugated mirror for k > nw/2)
+        if (k == 0) v = cmake(a.x, b.x);         // column 0 is real: its value sits in .x
+        if (k == C::NW / 2) v = cmake(a.y, b.y);  // column nw/2 is real: packed into .y of slot 0
+        wv[m] = v;
+      }
+      group_fft<C::EW, C::TGW, +1>(wv, tr, twr, rbuf);
+      float4 iv[NV / 4];
+#pragma unroll
+      for (int i = 0; i < NV / 4; ++i) iv[i] = inv4[(rr * (NV / 4) + i) * kThreads + tid];
+      const float* ivf = reinterpret_cast<const float*>(iv);
+#pragma unroll
+      for (int pp = 0; pp < C::PPW; ++pp) {
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+          const cf v = wv[pp + C::PPW * s];
+          const int e = (pp * KW + s) * 2;
+          const float va = v.x * ivf[e], vb = v.y * ivf[e + 1];
+          acc[rr][e] += va;
+          acc[rr][e + 1] += vb;
+          if (maps_out) {
+            const int n2 = tr + C::TGW * pp + C::EW * s;
+            const int n1 = 2 * (rr * C::PPR + gr);
+            if (n2 < g.iw && n1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1) * g.iw + n2] = va;
+            if (n2 < g.iw && n1 + 1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1 + 1) * g.iw + n2] = vb;
+          }
+        }
+      }
+    }
+    __syncthreads();  // R is rewritten by the next channel
+  }
+
+  // Slots outside the ih x iw map carry 1/sigma = 0 and stay 0; the score is floored at 0 anyway
+  // (similarity.py:355), so they cannot change the result.
+  float best = 0.0f;
+#pragma unroll
+  for (int r = 0; r < RR; ++r)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) best = fmaxf(best, acc[r][e]);
+  best = block_max(best, red);
+  if (tid == 0 && scores) {
+    const float s = best / static_cast<float>(g.channels);
+    float* dst = scores + static_cast<size_t>(qi) * ld + col0 + gi_item;
+    const float prev = accumulate ? *dst : 0.0f;
+    *dst = s > prev ? s : prev;
+  }
+}
+
+// ============================================================================================
+// Host side: configurations, LDS layouts, dispatch
+// ============================================================================================
+struct PrepFftLds {
+  size_t x0_off, f_off, xbuf_off, total;
+  int f_stride;
+};
+template <class C>
+PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
+  const int h = is_query ? g.th : g.ih, w = is_query ? g.tw : g.iw;
+  PrepFftLds l;
+  l.x0_off = 64;
+  l.f_off = align_up(l.x0_off + sizeof(float) * h * w, 16);
+  l.f_stride = C::NW / 2 + 1;
+  const size_t f_bytes = sizeof(cf) * static_cast<size_t>(2 * ((h + 1) / 2)) * l.f_stride;
+  l.xbuf_off = align_up(l.f_off + f_bytes, 16);
+  const size_t fft_total = l.xbuf_off + sizeof(cf) * C::XBUF;
+  const size_t sat_total = is_query ? 0 : l.f_off + sizeof(double) * (h + 1) * (w + 1);
+  l.total = fft_total > sat_total ? fft_total : sat_total;
+  return l;
+}
+
+struct PairFftLds {
+  size_t r_off, xbuf_off, total;
+};
+template <class C>
+PairFftLds pair_fft_lds(const NccGeom& g) {
+  PairFftLds l;
+  l.r_off = 64;
+  l.xbuf_off = align_up(l.r_off + sizeof(cf) * static_cast<size_t>(g.r_rows) * g.r_stride, 16);
+  l.total = l.xbuf_off + sizeof(cf) * C::XBUF;
+  return l;
+}
+
+// One entry per instantiated (nh, nw) grid.
+struct FftEntry {
+  int nh, nw, eh, tgh, ew, tgw;
+  int rr_tight, kw_tight, rr_loose, kw_loose;
+  size_t (*prep_lds_total)(const NccGeom&, bool);
+  size_t (*pair_lds_total)(const NccGeom&);
+  int (*prep)(const NccGeom&, bool, const void*, int64_t, void*, const cf*, const cf*, hipStream_t);
+  int (*pair)(const NccGeom&, bool, const void*, int64_t, const void*, int64_t, float*, int64_t, int64_t, int, float*,
+              const cf*, const cf*, hipStream_t);
+};
+
+template <class C>
+constexpr int rr_tight() { return (C::NH / 4 + C::PPR - 1) / C::PPR; }
+template <class C>
+constexpr int rr_loose() { return (C::NH / 2 + C::PPR - 1) / C::PPR; }
+
+template <class C>
+size_t prep_lds_total_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q).total; }
+template <class C>
+size_t pair_lds_total_t(const NccGeom& g) { return pair_fft_lds<C>(g).total; }
+
+template <class C>
+int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h, const cf* tw_w,
+           hipStream_t stream) {
+  const PrepFftLds l = prep_fft_lds<C>(g, is_query);
+  const size_t item_bytes = is_query ? prepared_query_item_bytes(g, SPR_NCC_FFT) : prepared_gallery_item_bytes(g, SPR_NCC_FFT);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsLimit);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads),
+                     l.total, stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes, tw_h,
+                     tw_w, static_cast<unsigned>(l.x0_off), static_cast<unsigned>(l.f_off),
+                     static_cast<unsigned>(l.xbuf_off), l.f_stride);
+  return check_launch("prep_fft_kernel");
+}
+
+template <class C, int RR, int KW>
+int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
+                int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, hipStream_t stream) {
+  const PairFftLds l = pair_fft_lds<C>(g);
+  const int64_t tiles = static_cast<int64_t>(ceil_div(static_cast<int>(nq), kTileQ)) * ceil_div(static_cast<int>(ng), kTileG);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
+                     dim3(kThreads), l.total, stream, g, static_cast<const unsigned char*>(pq),
+                     prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
+                     prepared_gallery_item_bytes(g, SPR_NCC_FFT), static_cast<int>(nq), static_cast<int>(ng), scores,
+                     static_cast<long long>(ld), static_cast<long long>(col0), accumulate, maps_out, tw_h, tw_w,
+                     static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off));
+  return check_launch("pair_fft_kernel");
+}
+
+template <class C>
+int pair_t(const NccGeom& g, bool tight, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+           int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
+           hipStream_t stream) {
+  if (tight)
+    return pair_launch<C, rr_tight<C>(), C::TGW / 2>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h,
+                                                     tw_w, stream);
+  return pair_launch<C, rr_loose<C>(), C::TGW>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                               stream);
+}
+
+template <class C>
+constexpr FftEntry entry() {
+  return FftEntry{C::NH,          C::NW,          C::EH,         C::TGH,       C::EW,
+                  C::TGW,         rr_tight<C>(),  C::TGW / 2,    rr_loose<C>(), C::TGW,
+                  prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C>};
+}
+
+// (E, TG) factorisations: 256 = 16*16, 128 = 16*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
+const FftEntry kEntries[] = {
+    entry<Cfg<8, 4, 4, 4>>(),      // 32 x 16
+    entry<Cfg<8, 4, 8, 4>>(),      // 32 x 32
+    entry<Cfg<8, 8, 8, 4>>(),      // 64 x 32
+    entry<Cfg<8, 8, 8, 8>>(),      // 64 x 64
+    entry<Cfg<16, 8, 8, 8>>(),     // 128 x 64
+    entry<Cfg<16, 8, 16, 8>>(),    // 128 x 128
+    entry<Cfg<16, 16, 16, 8>>(),   // 256 x 128
+};
+
+const FftEntry* find_entry(int nh, int nw) {
+  for (const FftEntry& e : kEntries)
+    if (e.nh == nh && e.nw == nw) return &e;
+  return nullptr;
+}
+
+inline int fft_need(int img, int tpl) {
+  const int c = tpl / 2;
+  const int a = img + c, b = img + tpl - 1 - c;
+  return a > b ? a : b;
+}
+
+bool fill_geometry(NccGeom& g, const FftEntry& e) {
+  g.nh = e.nh; g.nw = e.nw; g.eh = e.eh; g.tgh = e.tgh; g.ew = e.ew; g.tgw = e.tgw;
+  const int cpr = kThreads / e.tgh, ppr = kThreads / e.tgw;
+  g.rounds_c = ceil_div(e.nw / 2, cpr);
+  const bool tight = g.ih <= e.nh / 2 && g.iw <= e.nw / 2;
+  g.tight = tight ? 1 : 0;
+  g.sh = ceil_div(g.ih, e.eh);  // kept outputs per column sub-transform (<= tgh/2 when tight)
+  g.r_rows = e.eh * g.sh;
+  g.r_stride = e.nw / 2 + 4;
+  g.rounds_r = ceil_div(g.r_rows / 2, ppr);
+  g.keep_w = tight ? e.kw_tight : e.kw_loose;
+  if (g.rounds_r > (tight ? e.rr_tight : e.rr_loose)) return false;
+  g.spec_per_chan = g.rounds_c * e.eh * kThreads + e.nh;
+  g.inv_per_chan = g.rounds_r * (e.ew / e.tgw) * g.keep_w * 2 * kThreads;
+  if (g.ih * g.iw > kMaxPixPerThread * kThreads || g.th * g.tw > kMaxPixPerThread * kThreads) return false;
+  if (e.prep_lds_total(g, true) > static_cast<size_t>(kLdsLimit)) return false;
+  if (e.prep_lds_total(g, false) > static_cast<size_t>(kLdsLimit)) return false;
+  if (e.pair_lds_total(g) > static_cast<size_t>(kLdsLimit)) return false;
+  return true;
+}
+
+}  // namespace
+
+bool fft_geometry(NccGeom& g) {
+  const int need_h = fft_need(g.ih, g.th), need_w = fft_need(g.iw, g.tw);
+  // the template must also fit the grid (it always does when the image does not alias, except
+  // for templates larger than the image)
+  const int min_h = need_h > g.th ? need_h : g.th, min_w = need_w > g.tw ? need_w : g.tw;
+  const FftEntry* best = nullptr;
+  NccGeom best_g = g;
+  for (const FftEntry& e : kEntries) {
+    if (e.nh < min_h || e.nw < min_w) continue;
+    if (best && static_cast<long long>(e.nh) * e.nw >= static_cast<long long>(best->nh) * best->nw) continue;
+    NccGeom trial = g;
+    if (!fill_geometry(trial, e)) continue;
+    best = &e;
+    best_g = trial;
+  }
+  if (!best) return false;
+  g = best_g;
+  return true;
+}
+
+int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
+                    const cf* tw_w, hipStream_t stream) {
+  if (n == 0) return SPR_OK;
+  const FftEntry* e = find_entry(g.nh, g.nw);
+  if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
+  return e->prep(g, is_query, maps, n, prepared, tw_h, tw_w, stream);
+}
+
+int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+                    int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
+                    hipStream_t stream) {
+  if (nq == 0 || ng == 0) return SPR_OK;
+  const FftEntry* e = find_entry(g.nh, g.nw);
+  if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
+  return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, stream);
+}
+
+}  // namespace spr

@@ -1,0 +1,127 @@
+// Per-channel preparation shared by the direct and FFT methods (one workgroup = one channel of
+// one item):  crop + centre (similarity.py:92-93, 48-49), template energy (:67) and the float64
+// window statistics that give the 1/sigma map of a search image (:57-65).
+#pragma once
+#include "spr_common.h"
+
+namespace spr {
+
+constexpr int kMaxPixPerThread = 48;  // cropped maps of up to 48*256 = 12288 pixels
+
+// x0[y*w + x] = crop(map)[y][x] - mean(crop(map)), float32 arithmetic on a float64-accumulated mean.
+// Returns after a workgroup barrier.
+__device__ __forceinline__ void load_centred(const void* maps, size_t chan_base, int raw_w, int crop, int h, int w,
+                                             int dtype, float* x0, double* red) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int n = h * w;
+  double s = 0.0;
+  for (int i = tid; i < n; i += kThreads) {
+    const int y = i / w, x = i - y * w;
+    const float v = load_feature(maps, chan_base + static_cast<size_t>(y + crop) * raw_w + (x + crop), dtype);
+    x0[i] = v;
+    s += static_cast<double>(v);
+  }
+  const double total = block_sum(s, red);
+  const float mean = static_cast<float>(total / static_cast<double>(n));
+  for (int i = tid; i < n; i += kThreads) x0[i] = x0[i] - mean;
+  __syncthreads();
+}
+
+// 1/sqrt(sum x0^2) as float (0 for an all-zero map: the reference's 0/0 -> NaN -> 0, :68-70).
+__device__ __forceinline__ float template_scale(const float* x0, int n, double* red) {
+  const int tid = static_cast<int>(threadIdx.x);
+  double s = 0.0;
+  for (int i = tid; i < n; i += kThreads) {
+    const float v = x0[i];
+    const float sq = v * v;  // np.square keeps float32 (:67)
+    s += static_cast<double>(sq);
+  }
+  const float energy = static_cast<float>(block_sum(s, red));
+  return energy > 0.0f ? static_cast<float>(1.0 / sqrt(static_cast<double>(energy))) : 0.0f;
+}
+
+// Summed-area table of x0 (or of fl32(x0^2)) in float64: sat[(y)*(w+1) + x] = sum of rows < y, cols < x.
+__device__ __forceinline__ void build_sat(const float* x0, int h, int w, double* sat, bool squared) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int stride = w + 1;
+  for (int x = tid; x <= w; x += kThreads) sat[x] = 0.0;
+  for (int y = tid; y < h; y += kThreads) {
+    double run = 0.0;
+    double* row = sat + static_cast<size_t>(y + 1) * stride;
+    row[0] = 0.0;
+    for (int x = 0; x < w; ++x) {
+      const float v = x0[y * w + x];
+      if (squared) {
+        const float sq = v * v;
+        run += static_cast<double>(sq);
+      } else {
+        run += static_cast<double>(v);
+      }
+      row[x + 1] = run;
+    }
+  }
+  __syncthreads();
+  for (int x = tid; x <= w; x += kThreads) {
+    double run = 0.0;
+    for (int y = 1; y <= h; ++y) {
+      run += sat[static_cast<size_t>(y) * stride + x];
+      sat[static_cast<size_t>(y) * stride + x] = run;
+    }
+  }
+  __syncthreads();
+}
+
+// Sum over the th x tw window that 'same'-mode correlation places at output pixel (y, x),
+// clipped to the h x w image (zero padding contributes nothing).
+__device__ __forceinline__ double window_sum(const double* sat, int h, int w, int th, int tw, int y, int x) {
+  const int stride = w + 1;
+  int y0 = y - th / 2, y1 = y0 + th, x0 = x - tw / 2, x1 = x0 + tw;
+  y0 = y0 < 0 ? 0 : (y0 > h ? h : y0);
+  y1 = y1 < 0 ? 0 : (y1 > h ? h : y1);
+  x0 = x0 < 0 ? 0 : (x0 > w ? w : x0);
+  x1 = x1 < 0 ? 0 : (x1 > w ? w : x1);
+  return sat[static_cast<size_t>(y1) * stride + x1] - sat[static_cast<size_t>(y0) * stride + x1] -
+         sat[static_cast<size_t>(y1) * stride + x0] + sat[static_cast<size_t>(y0) * stride + x0];
+}
+
+// inv_sigma for every pixel of the centred map x0 (h x w), for a th x tw template:
+// var = S2 - S1^2/(th*tw) in float64, var <= 0 -> 0 (the reference clamps negatives to 0 and
+// turns the resulting division by zero into 0, :65, :70).  `store(i, value)` receives pixel
+// i = y*w + x.  `sat` needs (h+1)*(w+1) doubles of LDS.
+template <class Store>
+__device__ __forceinline__ void inv_sigma_map(const float* x0, int h, int w, int th, int tw, double* sat, Store store) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int n = h * w;
+  double s1[kMaxPixPerThread];
+  build_sat(x0, h, w, sat, false);
+#pragma unroll
+  for (int k = 0; k < kMaxPixPerThread; ++k) {
+    const int i = tid + k * kThreads;
+    s1[k] = 0.0;
+    if (i < n) {
+      const int y = i / w, x = i - y * w;
+      s1[k] = window_sum(sat, h, w, th, tw, y, x);
+    }
+  }
+  __syncthreads();
+  build_sat(x0, h, w, sat, true);
+  const double inv_n = 1.0 / (static_cast<double>(th) * static_cast<double>(tw));
+#pragma unroll
+  for (int k = 0; k < kMaxPixPerThread; ++k) {
+    const int i = tid + k * kThreads;
+    if (i < n) {
+      const int y = i / w, x = i - y * w;
+      const double s2 = window_sum(sat, h, w, th, tw, y, x);
+      const double var = s2 - s1[k] * s1[k] * inv_n;
+      float inv = 0.0f;
+      if (var > 0.0) {
+        inv = static_cast<float>(1.0 / sqrt(var));
+        if (!(inv <= 3.0e38f)) inv = 0.0f;  // overflow of a denormal variance: treat as non-finite -> 0
+      }
+      store(i, inv);
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace spr

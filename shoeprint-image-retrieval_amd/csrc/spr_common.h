@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units of libshoeprint_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/shoeprint_mi355x.h"
+#include <spr_intrinsics.h>  // angle form: the CPU-emulation test build shadows it by include path
+
+namespace spr {
+
+constexpr int kThreads = 256;          // work-items per workgroup of every NCC kernel (4 waves)
+constexpr int kLdsLimit = 160 * 1024;  // LDS per CU on gfx950
+
+struct cf {  // complex<float>, 8-byte aligned so LDS/global accesses are single b64 ops
+  float x, y;
+};
+static_assert(sizeof(cf) == 8, "cf must be 8 bytes");
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of one plan, passed by value to the kernels.
+//
+// Cropped template (query) maps are th x tw, cropped search (gallery) maps ih x iw.  'same'-mode
+// output (similarity.py:55, scipy 'same') has the search map's size; output pixel (y, x)
+// correlates the template with the window whose top-left corner is (y - th/2, x - tw/2).
+struct NccGeom {
+  int channels;
+  int q_h, q_w, g_h, g_w;  // raw map sizes as stored by the caller
+  int crop;
+  int th, tw, ih, iw;  // cropped sizes
+  int dtype;
+  // FFT method only ------------------------------------------------------------------------
+  int nh, nw;          // FFT grid (rows, cols); nh = eh*tgh, nw = ew*tgw
+  int eh, tgh, ew, tgw;
+  int tight;           // 1: ih <= nh/2 and iw <= nw/2 (the pruned kernel variant), 0: general variant
+  int rounds_c;        // column-pass rounds of (kThreads/tgh) columns covering nw/2 columns
+  int sh;              // kept outputs per column sub-transform: rows 0 .. eh*sh-1 cover ih
+  int r_rows;          // eh*sh rows of the intermediate LDS image
+  int r_stride;        // its row stride in complex elements
+  int rounds_r;        // row-pass rounds of (kThreads/tgw) row pairs covering r_rows/2 pairs (r_rows is even)
+  int keep_w;          // kept outputs per row sub-transform (covers iw)
+  int spec_per_chan;   // complex elements of one channel's spectrum (tiled layout)
+  int inv_per_chan;    // floats of one channel's 1/sigma map in pair-kernel register order
+  // direct method only ---------------------------------------------------------------------
+  int pad_h, pad_w;    // zero-padded search map: ih+th-1, iw+tw-1
+  int strips_per_row;  // strips of kStrip output pixels per output row
+  int strips_per_thread;
+};
+
+constexpr int kStrip = 8;  // output pixels per register strip in the direct kernel
+
+struct spr_ncc_plan_impl;
+
+// Launchers (each in its own .hip file).  All enqueue on `stream` and return SPR_OK / SPR_ERR_HIP.
+int launch_prep_direct(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared,
+                       hipStream_t stream);
+int launch_pair_direct(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+                       int64_t ld, int64_t col0, int accumulate, float* maps_out, hipStream_t stream);
+int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
+                    const cf* tw_w, hipStream_t stream);
+int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+                    int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
+                    hipStream_t stream);
+bool fft_geometry(NccGeom& g);     // fills the FFT fields; false if no instantiated kernel fits
+bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps do not fit LDS
+
+// Prepared-buffer sizes (bytes per item), both 256-byte multiples.
+size_t prepared_query_item_bytes(const NccGeom& g, int method);
+size_t prepared_gallery_item_bytes(const NccGeom& g, int method);
+
+// Load one feature value of any supported storage type as float.
+__device__ __forceinline__ float load_feature(const void* base, size_t idx, int dtype) {
+  if (dtype == SPR_F32) return static_cast<const float*>(base)[idx];
+  const uint16_t bits = static_cast<const uint16_t*>(base)[idx];
+  if (dtype == SPR_BF16) {
+    union { uint32_t u; float f; } v;
+    v.u = static_cast<uint32_t>(bits) << 16;
+    return v.f;
+  }
+  union { uint16_t u; _Float16 h; } v;
+  v.u = bits;
+  return static_cast<float>(v.h);
+}
+
+// Workgroup reductions over kThreads work-items; `scratch` holds kThreads/64 values.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  const int tid = static_cast<int>(threadIdx.x);
+  __syncthreads();  // scratch may still be read by a previous reduction
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < kThreads / 64; ++w) s += scratch[w];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+  const int tid = static_cast<int>(threadIdx.x);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  float s = scratch[0];
+  for (int w = 1; w < kThreads / 64; ++w) s = fmaxf(s, scratch[w]);
+  return s;
+}
+
+}  // namespace spr

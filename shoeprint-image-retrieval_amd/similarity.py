@@ -1,0 +1,320 @@
+"""Query-vs-gallery NCC scoring and ranking on MI355X — host mirror of the reference scorer.
+
+Drop-in for ``src/shoeprint_image_retrieval/similarity.py`` of the reference:
+
+* ``compare_maps(shoemark_maps, shoeprint_maps, matching_pairs, config)``  (similarity.py:129-134)
+* ``get_similarity(shoemark, shoeprint)``                                  (similarity.py:75-78)
+* ``normxcorr(template, image, mode="same")``                              (similarity.py:26-31)
+
+with the same argument meaning, return types and error behaviour, computed by the HIP
+library behind the C ABI of ``include/shoeprint_mi355x.h`` (see ``_lib.py``).  The reference
+forks ``n_processes`` CPU workers over query chunks (similarity.py:146-197); here every
+(query, gallery) pair is a workgroup of one kernel launch, so ``n_processes`` is accepted
+and ignored.  There is no CPU fallback: without the library or a GPU these functions raise.
+
+``NccScorer`` is the device-level interface used by ``bench.py`` and the multi-GPU driver:
+it keeps features, prepared spectra and the score matrix resident in HBM.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import NCC_AUTO, NCC_DIRECT, NCC_FFT, NccShape
+
+CROP = 2  # similarity.py:92-93
+_METHODS = {"auto": NCC_AUTO, "fft": NCC_FFT, "direct": NCC_DIRECT}
+_DTYPES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float16): _lib.F16}
+
+
+class _Plan:
+    """Owns one spr_ncc_plan (one (query shape, gallery shape) class)."""
+
+    def __init__(self, lib: _lib.Library, channels: int, q_hw, g_hw, crop: int, dtype: int, method: int):
+        self.lib = lib
+        shape = NccShape(channels, q_hw[0], q_hw[1], g_hw[0], g_hw[1], crop, dtype, method)
+        handle = C.c_void_p()
+        lib.check(lib.spr_ncc_plan_create(C.byref(shape), C.byref(handle)))
+        self.handle = handle
+        self.channels, self.q_hw, self.g_hw, self.crop = channels, tuple(q_hw), tuple(g_hw), crop
+        self.method = lib.spr_ncc_plan_method(handle)
+        rows, cols = C.c_int32(), C.c_int32()
+        lib.check(lib.spr_ncc_plan_fft_size(handle, C.byref(rows), C.byref(cols)))
+        self.fft_size = (rows.value, cols.value)
+        self.query_item_bytes = lib.spr_ncc_query_bytes(handle, 1)
+        self.gallery_item_bytes = lib.spr_ncc_gallery_bytes(handle, 1)
+
+    def close(self):
+        if self.handle:
+            self.lib.spr_ncc_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_item_list(maps) -> tuple[list | None, Any]:
+    """Normalise the accepted inputs: returns (list of per-item arrays, None) for host lists /
+    host arrays, or (None, device_array) for an already device-resident [N,C,h,w] batch."""
+    if isinstance(maps, np.ndarray):
+        if maps.ndim != 4:
+            raise ValueError("a feature batch must be [N, C, h, w]")
+        return list(maps), None
+    if isinstance(maps, (list, tuple)):
+        return list(maps), None
+    return None, maps
+
+
+class NccScorer:
+    """Scores queries against a gallery with the HIP NCC kernels; everything stays in HBM.
+
+    Parameters
+    ----------
+    device : backend object (default ``TorchDevice()``: PyTorch-ROCm on the current GPU)
+    library: ``_lib.Library`` (default: the in-tree libshoeprint_mi355x.so)
+    method : "auto" | "fft" | "direct"  (pair-kernel choice, see the C header)
+    max_prepared_bytes: HBM budget for the prepared form of one gallery chunk (default: a third
+        of the free memory, at most 64 GiB); larger galleries are processed chunk by chunk.
+    """
+
+    def __init__(self, device=None, library: _lib.Library | None = None, method: str = "auto",
+                 max_prepared_bytes: int | None = None, crop: int = CROP):
+        self.lib = library or _lib.load_library()
+        if device is None:
+            from .device import TorchDevice
+
+            device = TorchDevice()
+        self.dev = device
+        self.method = _METHODS[method]
+        self.crop = crop
+        self.max_prepared_bytes = max_prepared_bytes
+        self._plans: dict[tuple, _Plan] = {}
+
+    # ------------------------------------------------------------------ plans
+    def plan(self, channels: int, q_hw, g_hw, dtype=np.float32, crop: int | None = None) -> _Plan:
+        crop = self.crop if crop is None else crop
+        key = (channels, tuple(q_hw), tuple(g_hw), np.dtype(dtype).str, crop, self.method)
+        p = self._plans.get(key)
+        if p is None:
+            p = _Plan(self.lib, channels, q_hw, g_hw, crop, _DTYPES[np.dtype(dtype)], self.method)
+            self._plans[key] = p
+        return p
+
+    def close(self):
+        for p in self._plans.values():
+            p.close()
+        self._plans.clear()
+
+    # ------------------------------------------------------------------ device-level steps
+    def _budget(self) -> int:
+        if self.max_prepared_bytes is not None:
+            return int(self.max_prepared_bytes)
+        return max(256 << 20, min(self.dev.free_bytes() // 3, 64 << 30))
+
+    def prepare_queries(self, plan: _Plan, q_dev):
+        n = self.dev.shape(q_dev)[0]
+        out = self.dev.empty_bytes(max(1, plan.query_item_bytes * n))
+        self.lib.check(self.lib.spr_ncc_prepare_queries(plan.handle, self.dev.ptr(q_dev), n, self.dev.ptr(out),
+                                                        self.dev.stream()))
+        return out
+
+    def prepare_gallery(self, plan: _Plan, g_dev, out=None):
+        n = self.dev.shape(g_dev)[0]
+        if out is None:
+            out = self.dev.empty_bytes(max(1, plan.gallery_item_bytes * n))
+        self.lib.check(self.lib.spr_ncc_prepare_gallery(plan.handle, self.dev.ptr(g_dev), n, self.dev.ptr(out),
+                                                        self.dev.stream()))
+        return out
+
+    def score_prepared(self, plan: _Plan, pq, nq: int, pg, ng: int, scores, ld: int, col0: int,
+                       accumulate_max: bool = False):
+        self.lib.check(self.lib.spr_ncc_score(plan.handle, self.dev.ptr(pq), nq, self.dev.ptr(pg), ng,
+                                              self.dev.ptr(scores), ld, col0, 1 if accumulate_max else 0,
+                                              self.dev.stream()))
+
+    def gallery_chunk_items(self, plan: _Plan, n_gallery: int) -> int:
+        per_item = plan.gallery_item_bytes
+        return int(max(1, min(n_gallery, self._budget() // max(1, per_item), 65535)))
+
+    def scores_device(self, q_dev, g_dev, scores=None, accumulate_max: bool = False, plan: _Plan | None = None):
+        """[Q,G] float32 score matrix (device) of a uniform query batch [Q,C,h,w] against a uniform
+        gallery batch [G,C,h',w'], both already in HBM.  One step of the hot path."""
+        nq, c, qh, qw = self.dev.shape(q_dev)
+        ng, c2, gh, gw = self.dev.shape(g_dev)
+        if c != c2:
+            raise ValueError(f"channel mismatch: queries {c}, gallery {c2}")
+        if plan is None:
+            plan = self.plan(c, (qh, qw), (gh, gw))
+        if scores is None:
+            scores = self.dev.zeros((nq, ng), np.float32)
+        if nq == 0 or ng == 0:
+            return scores
+        pq = self.prepare_queries(plan, q_dev)
+        chunk = self.gallery_chunk_items(plan, ng)
+        pg = self.dev.empty_bytes(plan.gallery_item_bytes * chunk)
+        for start in range(0, ng, chunk):
+            n = min(chunk, ng - start)
+            self.prepare_gallery(plan, self.dev.narrow0(g_dev, start, n), out=pg)
+            for q0 in range(0, nq, 65535):
+                qn = min(65535, nq - q0)
+                self.score_prepared(plan, self._offset(pq, q0 * plan.query_item_bytes), qn, pg, n,
+                                    self.dev.narrow0(scores, q0, qn), ng, start, accumulate_max)
+        return scores
+
+    def _offset(self, byte_buf, nbytes: int):
+        return byte_buf if nbytes == 0 else self.dev.narrow0(byte_buf, nbytes, self.dev.shape(byte_buf)[0] - nbytes)
+
+    def ranks_device(self, scores, match_dev):
+        nq, ng = self.dev.shape(scores)
+        ranks = self.dev.zeros((max(nq, 1),), np.int32)
+        self.lib.check(self.lib.spr_rank_true_match(self.dev.ptr(scores), ng, nq, ng, self.dev.ptr(match_dev),
+                                                    self.dev.ptr(ranks), self.dev.stream()))
+        return self.dev.narrow0(ranks, 0, nq)
+
+    def ncc_maps_device(self, plan: _Plan, pq, pg):
+        ih, iw = plan.g_hw[0] - 2 * plan.crop, plan.g_hw[1] - 2 * plan.crop
+        out = self.dev.zeros((plan.channels, ih, iw), np.float32)
+        self.lib.check(self.lib.spr_ncc_maps(plan.handle, self.dev.ptr(pq), self.dev.ptr(pg), self.dev.ptr(out),
+                                             self.dev.stream()))
+        return out
+
+    # ------------------------------------------------------------------ list-of-arrays level
+    def score_matrix(self, shoemark_maps, shoeprint_maps, accumulate_into=None) -> np.ndarray:
+        """Host float32 [Q,G] matrix for the reference's list-of-arrays inputs, including ragged
+        sets (items of different spatial size): items are grouped by shape and every
+        (query shape, gallery shape) class is one plan."""
+        q_items, q_dev = _as_item_list(shoemark_maps)
+        g_items, g_dev = _as_item_list(shoeprint_maps)
+        if q_items is None and g_items is None:
+            scores = self.scores_device(q_dev, g_dev)
+            return self.dev.to_host(scores)
+        if q_items is None:
+            q_items = list(self.dev.to_host(q_dev))
+        if g_items is None:
+            g_items = list(self.dev.to_host(g_dev))
+        nq, ng = len(q_items), len(g_items)
+        out = np.zeros((nq, ng), dtype=np.float32) if accumulate_into is None else accumulate_into
+        if nq == 0 or ng == 0:
+            return out
+        q_groups = _group_by_shape(q_items)
+        g_groups = _group_by_shape(g_items)
+        for qshape, q_idx in q_groups.items():
+            q_batch = self.dev.to_device(_stack32(q_items, q_idx))
+            for gshape, g_idx in g_groups.items():
+                if qshape[0] != gshape[0]:
+                    raise ValueError(f"channel mismatch: query {qshape}, gallery {gshape}")
+                plan = self.plan(qshape[0], qshape[1:], gshape[1:])
+                pq = self.prepare_queries(plan, q_batch)
+                chunk = self.gallery_chunk_items(plan, len(g_idx))
+                for start in range(0, len(g_idx), chunk):
+                    idx = g_idx[start:start + chunk]
+                    g_batch = self.dev.to_device(_stack32(g_items, idx))
+                    pg = self.prepare_gallery(plan, g_batch)
+                    sub = self.dev.zeros((len(q_idx), len(idx)), np.float32)
+                    self.score_prepared(plan, pq, len(q_idx), pg, len(idx), sub, len(idx), 0)
+                    sub_h = self.dev.to_host(sub)
+                    block = out[np.ix_(q_idx, idx)]
+                    out[np.ix_(q_idx, idx)] = np.maximum(block, sub_h)
+        return out
+
+    def ranks(self, scores_host: np.ndarray, matching_pairs: Sequence[int]) -> np.ndarray:
+        nq, ng = scores_host.shape
+        if nq == 0:
+            return np.zeros(0, dtype=np.int32)
+        s_dev = self.dev.to_device(np.ascontiguousarray(scores_host, dtype=np.float32))
+        m_dev = self.dev.to_device(np.asarray(matching_pairs, dtype=np.int32))
+        ranks = self.dev.to_host(self.ranks_device(s_dev, m_dev)).astype(np.int32, copy=True)
+        if (ranks == 0).any():
+            # the reference's np.where(...)[0][0] raises IndexError when the id is not in the gallery
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+        return ranks
+
+
+def _group_by_shape(items) -> dict[tuple, list[int]]:
+    groups: dict[tuple, list[int]] = {}
+    for i, a in enumerate(items):
+        if a.ndim != 3:
+            raise ValueError("feature maps must be [C, h, w] (customtypes.py:11-14)")
+        groups.setdefault(tuple(a.shape), []).append(i)
+    return groups
+
+
+def _stack32(items, idx) -> np.ndarray:
+    return np.ascontiguousarray(np.stack([np.asarray(items[i], dtype=np.float32) for i in idx]))
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's call surface
+# ---------------------------------------------------------------------------------------------
+_default_scorer: NccScorer | None = None
+
+
+def default_scorer() -> NccScorer:
+    global _default_scorer
+    if _default_scorer is None:
+        _default_scorer = NccScorer()
+    return _default_scorer
+
+
+def compare_maps(
+    shoemark_maps: list[np.ndarray],
+    shoeprint_maps: list[np.ndarray],
+    matching_pairs: list[int],
+    config: dict,
+    *,
+    scorer: NccScorer | None = None,
+    progress: bool = False,
+) -> np.ndarray:
+    """Ranks (1-based, int32 [Q]) of every query's true match — reference similarity.py:129-227.
+
+    ``matching_pairs[i]`` is the index into ``shoeprint_maps`` of query i's true match;
+    ``config["comparison"]`` supplies ``n_processes`` (ignored: the GPU grid replaces the
+    process pool), ``rotations`` and ``scales``.
+    """
+    comp = config["comparison"]
+    rotations, scales = comp.get("rotations"), comp.get("scales")
+    if rotations is not None or scales is not None:
+        raise NotImplementedError(
+            "rotation/scale variants of the query maps (similarity.py:230-284) are the next row (f1) of "
+            "the hot-path scope; run with rotations = scales = \"\" for now"
+        )
+    scorer = scorer or default_scorer()
+    scores = scorer.score_matrix(shoemark_maps, shoeprint_maps)
+    ranks = scorer.ranks(scores, matching_pairs)
+    if progress:
+        for i, r in enumerate(ranks):
+            print(f"Print {i} true match ranked {r}")  # similarity.py:375
+    return ranks
+
+
+def get_similarity(shoemark: np.ndarray, shoeprint: np.ndarray, *, scorer: NccScorer | None = None) -> np.floating[Any]:
+    """max over positions of the channel-summed NCC maps, divided by the channel count
+    (similarity.py:75-108); both stacks are cropped by 2 pixels per edge first."""
+    scorer = scorer or default_scorer()
+    mark = np.ascontiguousarray(shoemark, dtype=np.float32)
+    prnt = np.ascontiguousarray(shoeprint, dtype=np.float32)
+    plan = scorer.plan(mark.shape[0], mark.shape[1:], prnt.shape[1:])
+    pq = scorer.prepare_queries(plan, scorer.dev.to_device(mark[None]))
+    pg = scorer.prepare_gallery(plan, scorer.dev.to_device(prnt[None]))
+    maps = scorer.dev.to_host(scorer.ncc_maps_device(plan, pq, pg)).astype(np.float64)
+    return np.max(maps.sum(axis=0)) / mark.shape[0]
+
+
+def normxcorr(template: np.ndarray, image: np.ndarray, mode: str = "same", *, scorer: NccScorer | None = None) -> np.ndarray:
+    """Normalised cross-correlation map of ``template`` over ``image`` (similarity.py:26-72)."""
+    if mode != "same":
+        raise NotImplementedError("only mode='same' is on the hot path (similarity.py:104)")
+    scorer = scorer or default_scorer()
+    t = np.ascontiguousarray(template, dtype=np.float32)
+    i = np.ascontiguousarray(image, dtype=np.float32)
+    plan = scorer.plan(1, t.shape, i.shape, crop=0)
+    pq = scorer.prepare_queries(plan, scorer.dev.to_device(t[None, None]))
+    pg = scorer.prepare_gallery(plan, scorer.dev.to_device(i[None, None]))
+    return scorer.dev.to_host(scorer.ncc_maps_device(plan, pq, pg))[0]

@@ -1,0 +1,272 @@
+// Test-only stand-in for <hip/hip_runtime.h>: runs HIP kernels on the CPU.
+//
+// NOT part of the product.  The product (shoeprint-image-retrieval_amd/csrc) is
+// single-source HIP compiled by hipcc for gfx950 only.  This header lets the SAME
+// sources be compiled by the host clang++ (tests/emu/build_emu.py puts tests/emu in front
+// of the include path) so that kernels can be executed, debugged and run under
+// UBSan/ASan in a container without a GPU ("run sanitizers on the CPU build only").
+//
+// Execution model: every workgroup runs on one OS thread; its work-items are ucontext
+// fibers scheduled round-robin.  __syncthreads() and the wave-level operations of
+// spr_intrinsics.h are real rendezvous points: a fiber yields to the scheduler and is
+// resumed only when every fiber of its scope (workgroup / 64-wide wave) has arrived, so
+// missing barriers show up as wrong results and divergent barriers as a reported deadlock.
+// Workgroups of one launch run concurrently on up to SPR_EMU_THREADS OS threads.
+#pragma once
+
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return {x, y}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef void* hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
+                     hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace hipemu {
+
+enum State { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+constexpr size_t kStackBytes = 256 * 1024;
+constexpr size_t kLdsBytes = 160 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  uint3 tid{};
+  int state = DONE;
+};
+
+struct BlockCtx {
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  int cur = 0;
+  int nthreads = 0;
+  std::function<void()> body;
+  unsigned char* lds = nullptr;
+  std::vector<uint64_t> xchg;  // one 8-byte slot per work-item for cross-lane ops
+  std::vector<float> xf;       // scratch for emulated MFMA operands: 2 floats per work-item
+};
+
+inline thread_local BlockCtx* t_blk = nullptr;
+inline thread_local uint3 t_threadIdx{}, t_blockIdx{};
+inline thread_local dim3 t_blockDim{}, t_gridDim{};
+
+inline void yield(int kind) {
+  BlockCtx* b = t_blk;
+  Fiber& f = b->fibers[b->cur];
+  f.state = kind;
+  swapcontext(&f.ctx, &b->sched);
+  t_threadIdx = f.tid;  // restored after other fibers ran
+}
+
+inline void fiber_main(unsigned lo, unsigned hi) {
+  BlockCtx* b = reinterpret_cast<BlockCtx*>(static_cast<uintptr_t>(lo) | (static_cast<uintptr_t>(hi) << 32));
+  b->body();
+  b->fibers[b->cur].state = DONE;
+  // returns to uc_link (the scheduler)
+}
+
+inline void run_block(BlockCtx& b, dim3 block) {
+  const int n = static_cast<int>(block.x * block.y * block.z);
+  if (static_cast<int>(b.fibers.size()) < n) {
+    size_t old = b.fibers.size();
+    b.fibers.resize(n);
+    for (size_t i = old; i < b.fibers.size(); ++i) b.fibers[i].stack = static_cast<char*>(std::malloc(kStackBytes));
+  }
+  b.nthreads = n;
+  b.xchg.assign(n, 0);
+  b.xf.assign(2 * static_cast<size_t>(n), 0.f);
+  t_blk = &b;
+  for (int i = 0; i < n; ++i) {
+    Fiber& f = b.fibers[i];
+    f.tid = uint3{static_cast<unsigned>(i % block.x), static_cast<unsigned>((i / block.x) % block.y),
+                  static_cast<unsigned>(i / (block.x * block.y))};
+    f.state = RUN;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStackBytes;
+    f.ctx.uc_link = &b.sched;
+    uintptr_t p = reinterpret_cast<uintptr_t>(&b);
+    makecontext(&f.ctx, reinterpret_cast<void (*)()>(fiber_main), 2, static_cast<unsigned>(p & 0xffffffffu),
+                static_cast<unsigned>(p >> 32));
+  }
+  for (;;) {
+    bool ran = false, all_done = true;
+    for (int i = 0; i < n; ++i) {
+      Fiber& f = b.fibers[i];
+      if (f.state == RUN) {
+        b.cur = i;
+        t_threadIdx = f.tid;
+        swapcontext(&b.sched, &f.ctx);
+        ran = true;
+      }
+      if (f.state != DONE) all_done = false;
+    }
+    if (all_done) break;
+    bool released = false;
+    // workgroup barrier: everyone arrived (or exited)
+    bool any_block = false, all_block = true;
+    for (int i = 0; i < n; ++i) {
+      int s = b.fibers[i].state;
+      if (s == WAIT_BLOCK) any_block = true;
+      else if (s != DONE) all_block = false;
+    }
+    if (any_block && all_block) {
+      for (int i = 0; i < n; ++i) if (b.fibers[i].state == WAIT_BLOCK) b.fibers[i].state = RUN;
+      released = true;
+    }
+    // wave-level rendezvous
+    for (int w0 = 0; w0 < n; w0 += 64) {
+      int w1 = std::min(n, w0 + 64);
+      bool any = false, all = true;
+      for (int i = w0; i < w1; ++i) {
+        int s = b.fibers[i].state;
+        if (s == WAIT_WAVE) any = true;
+        else if (s != DONE) all = false;
+      }
+      if (any && all) {
+        for (int i = w0; i < w1; ++i) if (b.fibers[i].state == WAIT_WAVE) b.fibers[i].state = RUN;
+        released = true;
+      }
+    }
+    if (!ran && !released) {
+      std::fprintf(stderr, "hipemu: deadlock — divergent barrier in block (%u,%u,%u)\n", t_blockIdx.x, t_blockIdx.y,
+                   t_blockIdx.z);
+      for (int i = 0; i < n; ++i)
+        if (b.fibers[i].state != DONE) std::fprintf(stderr, "  thread %d state %d\n", i, b.fibers[i].state);
+      std::abort();
+    }
+  }
+  t_blk = nullptr;
+}
+
+inline int worker_count() {
+  const char* e = std::getenv("SPR_EMU_THREADS");
+  int n = e ? std::atoi(e) : 8;
+  return std::max(1, n);
+}
+
+template <class Kernel, class... Args>
+inline void launch(Kernel kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/, Args... args) {
+  const size_t nblocks = static_cast<size_t>(grid.x) * grid.y * grid.z;
+  if (nblocks == 0 || block.x * block.y * block.z == 0) return;
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    BlockCtx ctx;
+    ctx.lds = static_cast<unsigned char*>(std::aligned_alloc(256, kLdsBytes));
+    ctx.body = [&]() { kernel(args...); };
+    for (;;) {
+      size_t bi = next.fetch_add(1);
+      if (bi >= nblocks) break;
+      t_gridDim = grid;
+      t_blockDim = block;
+      t_blockIdx = uint3{static_cast<unsigned>(bi % grid.x), static_cast<unsigned>((bi / grid.x) % grid.y),
+                         static_cast<unsigned>(bi / (static_cast<size_t>(grid.x) * grid.y))};
+      std::memset(ctx.lds, 0xCD, kLdsBytes);  // poison: reads of unwritten LDS show up
+      run_block(ctx, block);
+    }
+    for (auto& f : ctx.fibers) std::free(f.stack);
+    std::free(ctx.lds);
+  };
+  const int nw = static_cast<int>(std::min<size_t>(worker_count(), nblocks));
+  if (nw <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> pool;
+    for (int i = 0; i < nw; ++i) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+  }
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::t_threadIdx)
+#define blockIdx (hipemu::t_blockIdx)
+#define blockDim (hipemu::t_blockDim)
+#define gridDim (hipemu::t_gridDim)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hipemu::launch(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
+
+static inline void __syncthreads() { hipemu::yield(hipemu::WAIT_BLOCK); }
+
+// ---------------------------------------------------------------- runtime API subset
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+template <class F>
+static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+
+// ---------------------------------------------------------------- device-side helpers
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline float atomicAdd(float* p, float v) {
+  uint32_t* u = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+  for (;;) {
+    float f;
+    std::memcpy(&f, &old, 4);
+    f += v;
+    uint32_t nw;
+    std::memcpy(&nw, &f, 4);
+    if (__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+      std::memcpy(&f, &old, 4);
+      return f;
+    }
+  }
+}
+static inline int atomicMax(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}

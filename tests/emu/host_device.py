@@ -1,0 +1,49 @@
+"""Host-memory backend for driving the CPU-emulation build through the product's host code
+(test infrastructure: "device" buffers are numpy arrays, pointers are host pointers)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+class HostDevice:
+    name = "emu"
+
+    def empty(self, shape, dtype=np.float32):
+        return np.full(tuple(int(s) for s in np.atleast_1d(shape)), 0xCD, dtype=np.uint8).view(np.uint8)[: 0] if False else \
+            np.empty(tuple(int(s) for s in np.atleast_1d(shape)), dtype=dtype)
+
+    def empty_bytes(self, nbytes: int):
+        # poison so that reads of unwritten prepared data are visible
+        return np.full(int(nbytes), 0xCD, dtype=np.uint8)
+
+    def zeros(self, shape, dtype=np.float32):
+        return np.zeros(tuple(int(s) for s in np.atleast_1d(shape)), dtype=dtype)
+
+    def to_device(self, array):
+        return np.array(array, copy=True, order="C")
+
+    def to_host(self, buf):
+        return np.array(buf, copy=True)
+
+    def is_device_array(self, obj):
+        return False
+
+    def ptr(self, buf) -> int:
+        assert buf.flags["C_CONTIGUOUS"]
+        return int(buf.ctypes.data)
+
+    def stream(self) -> int:
+        return 0
+
+    def synchronize(self):
+        pass
+
+    def free_bytes(self) -> int:
+        return 8 << 30
+
+    def shape(self, buf):
+        return tuple(buf.shape)
+
+    def narrow0(self, buf, start, length):
+        return buf[int(start): int(start) + int(length)]

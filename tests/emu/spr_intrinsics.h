@@ -1,0 +1,78 @@
+// CPU-emulation shadow of csrc/spr_intrinsics.h (test infrastructure, see hip/hip_runtime.h here).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace spr {
+
+constexpr int kWave = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+inline unsigned char* dyn_lds() { return hipemu::t_blk->lds; }
+
+inline int linear_tid() {
+  return static_cast<int>(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+}
+inline int lane_id() { return linear_tid() & (kWave - 1); }
+
+inline void wave_sync() { hipemu::yield(hipemu::WAIT_WAVE); }
+
+template <class T>
+inline T exchange(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "exchange slot is 8 bytes");
+  hipemu::BlockCtx* b = hipemu::t_blk;
+  const int me = b->cur, w0 = me & ~(kWave - 1);
+  std::memcpy(&b->xchg[me], &v, sizeof(T));
+  hipemu::yield(hipemu::WAIT_WAVE);
+  int src = w0 + (src_lane & (kWave - 1));
+  if (src >= b->nthreads) src = me;
+  T r;
+  std::memcpy(&r, &b->xchg[src], sizeof(T));
+  hipemu::yield(hipemu::WAIT_WAVE);
+  return r;
+}
+inline float shfl_xor(float v, int mask) { return exchange(v, lane_id() ^ mask); }
+inline int shfl_xor(int v, int mask) { return exchange(v, lane_id() ^ mask); }
+inline double shfl_xor(double v, int mask) { return exchange(v, lane_id() ^ mask); }
+inline float shfl(float v, int src) { return exchange(v, src); }
+inline int shfl(int v, int src) { return exchange(v, src); }
+
+// Emulated MFMA: every lane publishes its A/B element, then computes its own D entries as the
+// k-ordered fmaf chain the hardware produces.
+inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+  hipemu::BlockCtx* blk = hipemu::t_blk;
+  const int me = blk->cur, w0 = me & ~(kWave - 1), l = me - w0;
+  blk->xf[2 * me] = a;
+  blk->xf[2 * me + 1] = b;
+  hipemu::yield(hipemu::WAIT_WAVE);
+  f32x4 d = c;
+  const int col = l & 15;
+  for (int j = 0; j < 4; ++j) {
+    const int row = (l >> 4) * 4 + j;
+    float acc = c[j];
+    for (int k = 0; k < 4; ++k) acc = std::fmaf(blk->xf[2 * (w0 + row + 16 * k)], blk->xf[2 * (w0 + col + 16 * k) + 1], acc);
+    d[j] = acc;
+  }
+  hipemu::yield(hipemu::WAIT_WAVE);
+  return d;
+}
+inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+  hipemu::BlockCtx* blk = hipemu::t_blk;
+  const int me = blk->cur, w0 = me & ~(kWave - 1), l = me - w0;
+  blk->xf[2 * me] = a;
+  blk->xf[2 * me + 1] = b;
+  hipemu::yield(hipemu::WAIT_WAVE);
+  f32x16 d = c;
+  const int col = l & 31;
+  for (int j = 0; j < 16; ++j) {
+    const int row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5);
+    float acc = c[j];
+    for (int k = 0; k < 2; ++k) acc = std::fmaf(blk->xf[2 * (w0 + row + 32 * k)], blk->xf[2 * (w0 + col + 32 * k) + 1], acc);
+    d[j] = acc;
+  }
+  hipemu::yield(hipemu::WAIT_WAVE);
+  return d;
+}
+
+}  // namespace spr

@@ -1,0 +1,164 @@
+"""Parity checks shared by the CPU-emulation tests (not gpu) and the MI355X tests (gpu).
+
+Every check drives the product's host code (similarity.py) over a C-ABI library — the
+emulation twin or the real gfx950 build — and compares with the oracle and the golden vectors.
+Tolerances: scores within 1e-4 of the reference (north_star); in practice the float32 FFT path is
+within ~1e-6 and that tighter bound is what is asserted for small maps.  Ranks: identical.
+"""
+
+import json
+import os
+
+import numpy as np
+
+from oracle import ncc_oracle as oracle
+from shoeprint_image_retrieval_amd import similarity, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4      # the contract (BASELINE.json: "NCC scores agree within 1e-4 fp32")
+TIGHT = 5e-6    # what the kernels are expected to reach on these sizes
+
+
+def _cfg(rot=None, sc=None):
+    return {"comparison": {"n_processes": 4, "rotations": rot, "scales": sc}}
+
+
+def check_golden_compare_maps(scorer, name):
+    z = np.load(os.path.join(GOLDEN, "compare_maps.npz"))
+    shape = [int(v) for v in z[f"{name}_shape"]]
+    nq, ng, c, h, w, seed = shape[:6]
+    kw = {"signal": shape[6], "noise": shape[7]} if len(shape) > 6 else {}
+    q, g, m = synth.dataset(seed, nq, ng, c, h, w, **kw)
+    mat = scorer.score_matrix(q, g)
+    assert mat.dtype == np.float32 and mat.shape == (nq, ng)
+    np.testing.assert_allclose(mat, z[f"{name}_matrix"], atol=TIGHT, rtol=0)
+    ranks = similarity.compare_maps(q, g, m, _cfg(), scorer=scorer)
+    assert ranks.dtype == np.int32
+    np.testing.assert_array_equal(ranks, z[f"{name}_ranks"])
+    return mat
+
+
+def check_golden_ragged(scorer):
+    z = np.load(os.path.join(GOLDEN, "compare_maps.npz"))
+    seed = 1236
+    rq = [synth.query_features(seed, i, i, 6, h, w) for i, (h, w) in enumerate([(18, 12), (16, 14), (18, 12)])]
+    rg = [synth.gallery_features(seed, i, 6, h, w) for i, (h, w) in
+          enumerate([(18, 12), (20, 12), (16, 14), (18, 12), (17, 15)])]
+    mat = scorer.score_matrix(rq, rg)
+    np.testing.assert_allclose(mat, z["ragged_matrix"], atol=TIGHT, rtol=0)
+    np.testing.assert_array_equal(similarity.compare_maps(rq, rg, [0, 2, 3], _cfg(), scorer=scorer), z["ragged_ranks"])
+
+
+def check_golden_normxcorr(scorer):
+    z = np.load(os.path.join(GOLDEN, "normxcorr_maps.npz"))
+    names = sorted({k.rsplit("_", 1)[0] for k in z.files if k.endswith("_out")})
+    for name in names:
+        t, i, ref = z[f"{name}_t"], z[f"{name}_i"], z[f"{name}_out"]
+        got = similarity.normxcorr(t, i, "same", scorer=scorer)
+        assert got.shape == ref.shape
+        if name == "const_image":
+            continue  # rounding noise normalised to O(1) in the reference itself (see test_oracle_golden)
+        if name in ("zero_template", "zero_image", "const_template"):
+            assert not got.any(), name  # degenerate maps give exact zeros (similarity.py:68-70)
+            continue
+        np.testing.assert_allclose(got, ref, atol=2e-5, rtol=0, err_msg=name)
+
+
+def check_golden_get_similarity(scorer, max_elems):
+    rows = json.load(open(os.path.join(GOLDEN, "get_similarity.json")))
+    done = 0
+    for r in rows:
+        c, h, w, seed = r["c"], r["h"], r["w"], r["seed"]
+        if c * h * w > max_elems:
+            continue
+        q = synth.query_features(seed, 0, 0, c, h, w)
+        g0 = synth.gallery_features(seed, 0, c, h, w)
+        g1 = synth.gallery_features(seed, 1, c, h, w)
+        for d in r["dead"]:
+            g0[d] = 0
+            g1[d] = 0
+        qd = q.copy()
+        if r["dead"]:
+            qd[r["dead"][0]] = 0
+        assert abs(similarity.get_similarity(q, g0, scorer=scorer) - r["sim_q0_g0"]) < TIGHT
+        assert abs(similarity.get_similarity(q, g1, scorer=scorer) - r["sim_q0_g1"]) < TIGHT
+        assert abs(similarity.get_similarity(qd, g0, scorer=scorer) - r["sim_qdead_g0"]) < TIGHT
+        done += 1
+    assert done > 0
+
+
+SHAPE_CASES = [  # (C, qh, qw, gh, gw): tight / general variants, odd sizes, template != image size
+    (3, 32, 16, 32, 16), (2, 40, 40, 40, 40), (2, 30, 17, 33, 15), (2, 16, 31, 17, 30),
+    (2, 20, 20, 50, 40), (2, 50, 40, 20, 20), (1, 13, 9, 20, 16), (2, 64, 32, 64, 32),
+]
+BIG_SHAPE_CASES = [(3, 128, 64, 128, 64), (2, 100, 70, 100, 70), (2, 90, 50, 120, 70)]
+
+
+def check_shape_case(scorer, case, tol=TIGHT):
+    c, qh, qw, gh, gw = case
+    same = (qh, qw) == (gh, gw)
+    q = [synth.query_features(7, i, i, c, qh, qw) if same else synth.gallery_features(8, 10 + i, c, qh, qw)
+         for i in range(2)]
+    g = [synth.gallery_features(7, i, c, gh, gw) for i in range(3)]
+    g[1][0] = 0  # dead gallery channel: contributes 0 but still counts in the divisor (similarity.py:96,108)
+    q[1][c - 1] = 0  # dead query channel
+    mat = scorer.score_matrix(q, g)
+    ref = oracle.similarity_matrix(q, g, precise=True)
+    np.testing.assert_allclose(mat, ref, atol=tol, rtol=0)
+
+
+def check_rank_kernel(scorer):
+    rng = np.random.default_rng(5)
+    for nq, ng in [(1, 1), (3, 7), (5, 300), (2, 1500)]:
+        s = rng.random((nq, ng)).astype(np.float32)
+        s[:, ::3] = s[:, :1]  # plenty of exact ties, some involving the true match
+        m = rng.integers(0, ng, nq)
+        got = scorer.ranks(s, m)
+        np.testing.assert_array_equal(got, oracle.ranks_from_matrix(s, m))
+    d = json.load(open(os.path.join(GOLDEN, "rank_and_scores.json")))
+    for case in d["rank"]:  # the reference's own _get_rank outputs (tie-free)
+        s = np.array(case["sims"], dtype=np.float32)[None].repeat(4, 0)
+        np.testing.assert_array_equal(scorer.ranks(s, case["matches"]), case["ranks"])
+    try:
+        scorer.ranks(np.zeros((2, 4), np.float32), [0, 4])
+    except IndexError:
+        pass
+    else:
+        raise AssertionError("a match index outside the gallery must raise IndexError (similarity.py:386)")
+
+
+def check_synth_twin(scorer, lib):
+    """The device generator is bit-identical to the numpy generator."""
+    dev = scorer.dev
+    c, h, w, seed = 3, 10, 7, 99
+    out = dev.zeros((4, c, h, w), np.float32)
+    lib.check(lib.spr_synth_gallery(dev.ptr(out), 2, 4, c, h, w, seed, dev.stream()))
+    got = dev.to_host(out)
+    for i in range(4):
+        np.testing.assert_array_equal(got[i], synth.gallery_features(seed, 2 + i, c, h, w))
+    match = np.array([5, 0, 3], dtype=np.int32)
+    m_dev = dev.to_device(match)
+    outq = dev.zeros((3, c, h, w), np.float32)
+    lib.check(lib.spr_synth_queries(dev.ptr(outq), 1, 3, dev.ptr(m_dev), c, h, w, seed, 3, 1, 6, dev.stream()))
+    gotq = dev.to_host(outq)
+    for i in range(3):
+        np.testing.assert_array_equal(gotq[i], synth.query_features(seed, 1 + i, int(match[i]), c, h, w, signal=1, noise=6))
+
+
+def check_variant_accumulate(scorer):
+    """accumulate_max keeps the running maximum over calls (similarity.py:364-367) and the floor at 0."""
+    dev = scorer.dev
+    q, g, _ = synth.dataset(3, 2, 3, 2, 16, 12, signal=1, noise=6)
+    qb, gb = dev.to_device(np.stack(q)), dev.to_device(np.stack(g))
+    scores = scorer.scores_device(qb, gb)
+    first = dev.to_host(scores).copy()
+    assert (first >= 0).all()
+    big = dev.to_device(np.full((2, 3), 0.9, np.float32))
+    scorer.scores_device(qb, gb, scores=big, accumulate_max=True)
+    np.testing.assert_array_equal(dev.to_host(big), np.maximum(first, np.float32(0.9)))
+    # anti-correlated pair: the raw similarity is negative, the stored score is the floor 0
+    a = np.zeros((1, 12, 10), np.float32)
+    a[0, 4:8, 3:7] = 1.0
+    mat = scorer.score_matrix([a], [1.0 - a])
+    ref = oracle.similarity_matrix([a], [1.0 - a], precise=True)
+    np.testing.assert_allclose(mat, ref, atol=TIGHT)

@@ -1,0 +1,147 @@
+"""`not gpu`: run the HIP kernels under the CPU emulation (tests/emu) against oracle + golden vectors,
+and check the C ABI of the real gfx950 build (symbols only — no compute without a GPU)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from emu_util import emu_library, emu_scorer
+from shoeprint_image_retrieval_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", params=["fft", "direct"])
+def scorer(request):
+    return emu_scorer(request.param)
+
+
+@pytest.mark.parametrize("name", ["tiny", "hard"])
+def test_emu_golden_compare_maps(scorer, name):
+    pc.check_golden_compare_maps(scorer, name)
+
+
+def test_emu_golden_ragged(scorer):
+    pc.check_golden_ragged(scorer)
+
+
+def test_emu_golden_normxcorr(scorer):
+    pc.check_golden_normxcorr(scorer)
+
+
+def test_emu_golden_get_similarity(scorer):
+    pc.check_golden_get_similarity(scorer, max_elems=64 * 32 * 16)
+
+
+@pytest.mark.parametrize("case", pc.SHAPE_CASES)
+def test_emu_shape_classes(scorer, case):
+    pc.check_shape_case(scorer, case)
+
+
+@pytest.mark.parametrize("case", pc.BIG_SHAPE_CASES)
+def test_emu_conv3_sized_maps_fft(case):
+    pc.check_shape_case(emu_scorer("fft"), case)
+
+
+def test_emu_rank_kernel(scorer):
+    pc.check_rank_kernel(scorer)
+
+
+def test_emu_synth_twin(scorer):
+    pc.check_synth_twin(scorer, emu_library())
+
+
+def test_emu_accumulate_and_floor(scorer):
+    pc.check_variant_accumulate(scorer)
+
+
+def test_emu_gallery_chunking_matches_single_pass():
+    from shoeprint_image_retrieval_amd import synth
+
+    q, g, _ = synth.dataset(11, 3, 9, 2, 16, 12, signal=1, noise=6)
+    whole = emu_scorer("fft").score_matrix(q, g)
+    one = emu_scorer("fft")
+    plan = one.plan(2, (16, 12), (16, 12))
+    chunked = emu_scorer("fft", max_prepared_bytes=2 * plan.gallery_item_bytes)
+    dev = chunked.dev
+    got = dev.to_host(chunked.scores_device(dev.to_device(np.stack(q)), dev.to_device(np.stack(g))))
+    np.testing.assert_array_equal(got, whole)
+
+
+def test_emu_auto_method_and_errors():
+    lib = emu_library()
+    sc = emu_scorer("auto")
+    assert sc.plan(4, (16, 12), (16, 12)).method == _lib.NCC_FFT
+    assert sc.plan(4, (16, 12), (16, 12)).fft_size == (32, 16)
+    assert sc.plan(256, (128, 64), (128, 64)).fft_size == (256, 128)  # VGG16 conv3_3 of a 512x256 print
+    assert sc.plan(512, (64, 32), (64, 32)).fft_size == (128, 64)     # conv4_3
+    assert sc.plan(512, (32, 16), (32, 16)).fft_size == (64, 32)      # conv5_3
+    with pytest.raises(_lib.SprError) as e:
+        sc.plan(4, (4, 4), (16, 12))  # vanishes under the 2-pixel crop
+    assert e.value.code == -2
+    with pytest.raises(_lib.SprError) as e:
+        sc.plan(4, (400, 300), (400, 300))  # nothing LDS-resident fits
+    assert e.value.code == -3
+    shape = _lib.NccShape(4, 16, 12, 16, 12, 2, 7, 0)
+    handle = ctypes.c_void_p()
+    assert lib.spr_ncc_plan_create(ctypes.byref(shape), ctypes.byref(handle)) == -1
+    assert b"dtype" in lib.spr_last_error()
+    assert lib.spr_rank_true_match(None, 4, 2, 4, None, None, None) == -1
+
+
+def test_float16_feature_storage():
+    """fp16 feature storage: parity = oracle on the same rounded features upcast to fp32."""
+    from oracle import ncc_oracle as oracle
+    from shoeprint_image_retrieval_amd import synth
+
+    sc = emu_scorer("fft")
+    dev = sc.dev
+    q, g, _ = synth.dataset(21, 2, 3, 3, 16, 12, signal=1, noise=6)
+    q16, g16 = np.stack(q).astype(np.float16), np.stack(g).astype(np.float16)
+    plan = sc.plan(3, (16, 12), (16, 12), dtype=np.float16)
+    pq = sc.prepare_queries(plan, dev.to_device(q16))
+    pg = sc.prepare_gallery(plan, dev.to_device(g16))
+    scores = dev.zeros((2, 3), np.float32)
+    sc.score_prepared(plan, pq, 2, pg, 3, scores, 3, 0)
+    ref = oracle.similarity_matrix(list(q16.astype(np.float32)), list(g16.astype(np.float32)), precise=True)
+    np.testing.assert_allclose(dev.to_host(scores), ref, atol=pc.TIGHT)
+
+
+# ------------------------------------------------------------------------- real library: ABI only
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "shoeprint_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_real_library_exports_every_declared_symbol():
+    path = _lib.DEFAULT_PATH
+    if not os.path.exists(path):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    cdll = ctypes.CDLL(path)
+    for name in _declared_symbols():
+        assert hasattr(cdll, name), name
+    cdll.spr_abi_version.restype = ctypes.c_int
+    assert cdll.spr_abi_version() == 1
+
+
+def test_product_refuses_to_run_without_gpu_or_library(tmp_path):
+    import torch
+
+    from shoeprint_image_retrieval_amd.device import TorchDevice
+
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.Library(str(tmp_path / "missing.so"))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            TorchDevice()

@@ -1,0 +1,148 @@
+"""`gpu`: the parity tests proper — the real gfx950 library on an MI355X, through the C ABI,
+against the oracle, the reference-generated golden vectors, and size-independent properties at
+BASELINE.json's full feature sizes."""
+
+import os
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from shoeprint_image_retrieval_amd import _lib
+
+    return _lib.load_library()  # raises if the in-tree .so is missing: no fallback
+
+
+@pytest.fixture(scope="module", params=["fft", "direct"])
+def scorer(request, lib):
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+
+    return NccScorer(method=request.param, library=lib)
+
+
+@pytest.fixture(scope="module")
+def fft_scorer(lib):
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+
+    return NccScorer(method="fft", library=lib)
+
+
+def test_native_library_is_loaded(lib):
+    assert os.path.basename(lib.path) == "libshoeprint_mi355x.so"
+    maps = open("/proc/self/maps").read()
+    assert "libshoeprint_mi355x.so" in maps
+
+
+@pytest.mark.parametrize("name", ["tiny", "hard"])
+def test_golden_compare_maps(scorer, name):
+    pc.check_golden_compare_maps(scorer, name)
+
+
+def test_golden_ragged(scorer):
+    pc.check_golden_ragged(scorer)
+
+
+def test_golden_normxcorr(scorer):
+    pc.check_golden_normxcorr(scorer)
+
+
+def test_golden_get_similarity_all_sizes(scorer):
+    # includes the 512x64x32 (conv4_3) and 256x128x64 (conv3_3) stacks
+    pc.check_golden_get_similarity(scorer, max_elems=1 << 40)
+
+
+@pytest.mark.parametrize("case", pc.SHAPE_CASES + pc.BIG_SHAPE_CASES)
+def test_shape_classes(scorer, case):
+    pc.check_shape_case(scorer, case, tol=2e-5)
+
+
+def test_golden_conv3_shaped_compare_maps(scorer):
+    """Q=2 x G=8 at the VGG16 conv3_3 shape: matrix and ranks from the real reference."""
+    pc.check_golden_compare_maps(scorer, "conv3")
+
+
+def test_rank_kernel(scorer):
+    pc.check_rank_kernel(scorer)
+
+
+def test_synth_twin(scorer, lib):
+    pc.check_synth_twin(scorer, lib)
+
+
+def test_accumulate_and_floor(scorer):
+    pc.check_variant_accumulate(scorer)
+
+
+def test_fft_and_direct_agree_on_device_generated_conv3_features(lib):
+    """Two independent HIP formulations on device-generated features (config-2 shape, fewer items)."""
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+    from shoeprint_image_retrieval_amd import synth
+
+    fft, direct = NccScorer(method="fft", library=lib), NccScorer(method="direct", library=lib)
+    dev = fft.dev
+    nq, ng, c, h, w, seed = 3, 6, 256, 128, 64, 77
+    g = dev.zeros((ng, c, h, w), np.float32)
+    q = dev.zeros((nq, c, h, w), np.float32)
+    m = dev.to_device(synth.default_matches(nq, ng))
+    lib.check(lib.spr_synth_gallery(dev.ptr(g), 0, ng, c, h, w, seed, dev.stream()))
+    lib.check(lib.spr_synth_queries(dev.ptr(q), 0, nq, dev.ptr(m), c, h, w, seed, 3, 1, 6, dev.stream()))
+    a = dev.to_host(fft.scores_device(q, g))
+    b = dev.to_host(direct.scores_device(q, g))
+    np.testing.assert_allclose(a, b, atol=2e-5, rtol=0)
+    np.testing.assert_array_equal(dev.to_host(fft.ranks_device(dev.to_device(a), m)),
+                                  dev.to_host(direct.ranks_device(dev.to_device(b), m)))
+
+
+def test_full_size_properties(fft_scorer, lib):
+    """Size-independent properties at the full conv3_3 size with a few hundred pairs:
+    (1) a gallery item scored against itself gives exactly the per-channel autocorrelation peak
+        ~1 (all channels alive), (2) scores are invariant to a positive rescaling of either side,
+    (3) permuting the gallery permutes the columns, (4) chunked == single pass, (5) scores in [0, 1+eps]."""
+    from shoeprint_image_retrieval_amd import synth
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+
+    sc = fft_scorer
+    dev = sc.dev
+    nq, ng, c, h, w, seed = 8, 40, 256, 128, 64, 4242
+    g = dev.zeros((ng, c, h, w), np.float32)
+    lib.check(lib.spr_synth_gallery(dev.ptr(g), 0, ng, c, h, w, seed, dev.stream()))
+    q = g[:nq].clone()
+    base = dev.to_host(sc.scores_device(q, g))
+    assert np.all(base >= 0) and np.all(base <= 1.0 + 1e-4)
+    np.testing.assert_allclose(np.diag(base[:, :nq]), 1.0, atol=2e-5)       # (1)
+    assert np.all(base[~np.eye(nq, ng, dtype=bool)] < 0.5)
+    scaled = dev.to_host(sc.scores_device(q * 4.0, g * 0.5))                # (2) power-of-two scales: exact inputs
+    np.testing.assert_allclose(scaled, base, atol=2e-6)
+    perm = np.random.default_rng(0).permutation(ng)
+    import torch
+    gp = g[torch.as_tensor(perm, device=g.device)]
+    np.testing.assert_array_equal(dev.to_host(sc.scores_device(q, gp)), base[:, perm])   # (3)
+    plan = sc.plan(c, (h, w), (h, w))
+    small = NccScorer(method="fft", library=lib, max_prepared_bytes=7 * plan.gallery_item_bytes)
+    np.testing.assert_array_equal(dev.to_host(small.scores_device(q, g)), base)          # (4)
+    ranks = dev.to_host(sc.ranks_device(dev.to_device(base), dev.to_device(np.arange(nq, dtype=np.int32))))
+    np.testing.assert_array_equal(ranks, np.ones(nq, np.int32))
+
+
+def test_oracle_sample_at_full_size(fft_scorer, lib):
+    """A sample of config-2 pairs (device-generated features) against the float64 oracle."""
+    from oracle import ncc_oracle as oracle
+    from shoeprint_image_retrieval_amd import synth
+
+    sc = fft_scorer
+    dev = sc.dev
+    nq, ng, c, h, w, seed = 2, 3, 256, 128, 64, 1234
+    m = synth.default_matches(nq, ng)
+    g = dev.zeros((ng, c, h, w), np.float32)
+    q = dev.zeros((nq, c, h, w), np.float32)
+    lib.check(lib.spr_synth_gallery(dev.ptr(g), 0, ng, c, h, w, seed, dev.stream()))
+    lib.check(lib.spr_synth_queries(dev.ptr(q), 0, nq, dev.ptr(dev.to_device(m)), c, h, w, seed, 3, 3, 2, dev.stream()))
+    got = dev.to_host(sc.scores_device(q, g))
+    ref = oracle.similarity_matrix(list(dev.to_host(q)), list(dev.to_host(g)), precise=True)
+    np.testing.assert_allclose(got, ref, atol=1e-5, rtol=0)
