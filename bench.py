@@ -184,7 +184,8 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        # the GPU box gives a one-GPU job a 16-core share of the host (nproc still reports every core)
+        cores = int(os.environ.get("SPR_CPU_CORES", min(os.cpu_count() or 1, 16)))
         sq = min(nq, cores)
         sg = args.cpu_sample_gallery or max(2, min(ng_local, int(round(20.0 * 1.9 * cores / max(1, sq)))))
         v, secs, cpu_ranks = cpu_baseline(sq, sg, cores)

@@ -70,6 +70,11 @@ class Library:
                 f"{self.path} not found: the HIP library is the product and has no fallback. "
                 "Build it with `make -C shoeprint-image-retrieval_amd/csrc` (or __graft_entry__.build())."
             )
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Device memory and
+        # streams come from torch, so its HIP runtime must be THE runtime of the process: import torch
+        # first, then our NEEDED libamdhip64.so.7 resolves to the copy that is already loaded.
+        import torch  # noqa: F401
+
         self.cdll = C.CDLL(self.path)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the ABI is incomplete
