@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--gallery-per-gpu", type=int, default=G_PER_GPU)
     ap.add_argument("--method", default="auto", choices=["auto", "fft", "direct"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true")
     ap.add_argument("--cpu-sample-gallery", type=int, default=0, help="gallery items in the CPU sample (0 = auto)")
     args = ap.parse_args()
 
@@ -193,6 +194,7 @@ def main():
                                "sample": f"Q={sq} x G={sg} of the same workload, oracle compare_maps with a "
                                          f"{cores}-process pool, {secs:.1f} s",
                                "gpu_over_cpu": round(value / v, 1)}
+    if rank == 0 and not args.no_parity_sample:
         # parity spot-check on pairs of the ACTUAL workload (features regenerated by the numpy twin)
         from oracle import ncc_oracle as oracle
         full_h = dev.to_host(full)

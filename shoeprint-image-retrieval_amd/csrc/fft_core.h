@@ -153,14 +153,16 @@ struct Dft {
   }
 };
 
-// Stride (in complex elements) between the p-rows of a group's exchange image, and the size of
-// one group's image.  The +1 keeps the strided reads of stage 2 off a single bank.
+// LDS image of one group's exchange: E rows of TG (+1 pad) complex values.  The +1 keeps the strided
+// stage-2 reads off a single bank; the group size is rounded up so that the 16/TG groups sharing one
+// 16-lane ds_write_b64 slice (and the groups sharing a 32-lane ds_read_b64 half) start on different banks:
+// group stride == TG (mod 16) complex elements.
 template <int E, int TG>
 struct GroupFftLds {
   static constexpr int kRow = TG + 1;
-  static constexpr int kGroupElems = E * kRow;
-  // elements for a whole workgroup of kThreads lanes
-  static constexpr int kBlockElems = (kThreads / TG) * kGroupElems;
+  static constexpr int kRaw = E * kRow;
+  static constexpr int kGroupElems = kRaw + ((TG % 16) - (kRaw % 16) + 16) % 16;
+  static constexpr int block_elems(int threads) { return (threads / TG) * kGroupElems; }
 };
 
 // Per-lane twiddles w_N^(DIR*t*p), p = 0..E-1, from the forward table tw[k] = exp(-2*pi*i*k/N).
@@ -176,6 +178,47 @@ __device__ __forceinline__ void load_twiddles(cf (&twr)[E], const cf* __restrict
 // The transform described at the top of this file.  `xbuf` is this group's exchange image
 // (GroupFftLds<E,TG>::kGroupElems complex values of LDS); every lane of the wave must call this
 // function together.  The image may be reused as soon as the function returns.
+// Twiddle source for group_fft: registers (loaded once per kernel) ...
+template <int E>
+struct RegTwiddles {
+  cf w[E];
+  __device__ __forceinline__ cf get(int p) const { return w[p]; }
+};
+// ... or a table in LDS holding w_N^(DIR*k), k = 0..N-1, read at use (saves 2E VGPRs per lane; lanes of a
+// group read entries t*p: a small strided access pattern, one ds_read_b64 per butterfly output).
+struct LdsTwiddles {
+  const cf* table;
+  int t;
+  __device__ __forceinline__ cf get(int p) const { return table[t * p]; }
+};
+
+template <int E, int TG, int DIR, class Tw>
+__device__ __forceinline__ void group_fft_tw(cf (&x)[E], int t, const Tw& tw, cf* xbuf) {
+  constexpr int PP = E / TG;
+  static_assert(E % TG == 0, "E must be a multiple of TG");
+  constexpr int kRow = GroupFftLds<E, TG>::kRow;
+  Dft<E, DIR>::run(x);
+#pragma unroll
+  for (int p = 0; p < E; ++p) {
+    const cf v = p == 0 ? x[0] : cmul(x[p], tw.get(p));
+    xbuf[p * kRow + t] = v;
+  }
+  wave_sync();
+  cf y[PP][TG];
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[(t + TG * pp) * kRow + tt];
+  }
+  wave_sync();
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+    Dft<TG, DIR>::run(y[pp]);
+#pragma unroll
+    for (int s = 0; s < TG; ++s) x[pp + PP * s] = y[pp][s];
+  }
+}
+
 template <int E, int TG, int DIR>
 __device__ __forceinline__ void group_fft(cf (&x)[E], int t, const cf (&twr)[E], cf* xbuf) {
   constexpr int PP = E / TG;

@@ -27,16 +27,29 @@
 namespace spr {
 namespace {
 
-template <int EH_, int TGH_, int EW_, int TGW_>
+// NT = work-items per workgroup of the PAIR kernel (the prep kernel always runs kThreads and
+// writes the prepared data in the pair kernel's lane order).
+template <int EH_, int TGH_, int EW_, int TGW_, int NT_ = kThreads>
 struct Cfg {
-  static constexpr int EH = EH_, TGH = TGH_, EW = EW_, TGW = TGW_;
+  static constexpr int EH = EH_, TGH = TGH_, EW = EW_, TGW = TGW_, NT = NT_;
   static constexpr int NH = EH * TGH, NW = EW * TGW;
-  static constexpr int CPR = kThreads / TGH;  // columns per column-pass round
-  static constexpr int PPR = kThreads / TGW;  // row pairs per row-pass round
+  static constexpr int CPR = NT / TGH;  // columns per column-pass round of the pair kernel
+  static constexpr int PPR = NT / TGW;  // row pairs per row-pass round of the pair kernel
   static constexpr int PPW = EW / TGW;
-  static constexpr int XBUF = GroupFftLds<EH, TGH>::kBlockElems > GroupFftLds<EW, TGW>::kBlockElems
-                                  ? GroupFftLds<EH, TGH>::kBlockElems
-                                  : GroupFftLds<EW, TGW>::kBlockElems;
+  static constexpr int COLS = NW / 2;   // columns of the intermediate image R (column nw/2 rides in column 0)
+  static constexpr int RC = (NW / 2 + CPR - 1) / CPR;  // column rounds per channel in the pair kernel
+  static constexpr int xbuf_elems(int threads) {
+    return GroupFftLds<EH, TGH>::block_elems(threads) > GroupFftLds<EW, TGW>::block_elems(threads)
+               ? GroupFftLds<EH, TGH>::block_elems(threads)
+               : GroupFftLds<EW, TGW>::block_elems(threads);
+  }
+  // Physical position of R[n1][j]: rows of COLS complex values, column XOR-swizzled by the row so that
+  // (a) the 16 lanes of a column transform writing rows t+16m of one column and (b) the four 8-lane row
+  // groups of a 32-lane half reading 8 consecutive columns of four different row pairs are conflict-free.
+  static __device__ __forceinline__ int r_index(int n1, int j) {
+    const int swz = ((n1 & 15) ^ (((n1 >> 1) & 3) << 3)) & (COLS - 1);
+    return n1 * COLS + (j ^ swz);
+  }
 };
 
 // ============================================================================================
@@ -82,7 +95,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
       const int pp = p / C::TGW, t = p - pp * C::TGW;
       const int e2 = (pp * g.keep_w + s) * 2 + ab;
       const int lane = giw * C::TGW + t;
-      inv[((rr * (nv / 4) + (e2 >> 2)) * kThreads + lane) * 4 + (e2 & 3)] = v;
+      inv[((rr * (nv / 4) + (e2 >> 2)) * C::NT + lane) * 4 + (e2 & 3)] = v;
     });
   }
 
@@ -93,9 +106,10 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     load_twiddles<C::EW, C::TGW, -1>(twr, tw_w, t);
     cf* gbuf = xbuf + giw * GroupFftLds<C::EW, C::TGW>::kGroupElems;
     const int pairs = (h + 1) / 2;
-    const int rounds = ceil_div(pairs, C::PPR);
+    constexpr int kPairsPerRound = kThreads / C::TGW;
+    const int rounds = ceil_div(pairs, kPairsPerRound);
     for (int rr = 0; rr < rounds; ++rr) {
-      const int pr = rr * C::PPR + giw;
+      const int pr = rr * kPairsPerRound + giw;
       const int ra = 2 * pr, rb = ra + 1;
       cf x[C::EW];
 #pragma unroll
@@ -136,9 +150,11 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     cf* gbuf = xbuf + gi * GroupFftLds<C::EH, C::TGH>::kGroupElems;
     const int rows_f = 2 * ((h + 1) / 2);
     const int cy = g.th / 2, cx = g.tw / 2;
-    for (int rc = 0; rc <= g.rounds_c; ++rc) {
-      const bool nyq = rc == g.rounds_c;
-      const int j = nyq ? C::NW / 2 : rc * C::CPR + gi;
+    constexpr int kColsPerRound = kThreads / C::TGH;
+    const int rounds = ceil_div(C::NW / 2, kColsPerRound);
+    for (int rc = 0; rc <= rounds; ++rc) {
+      const bool nyq = rc == rounds;
+      const int j = nyq ? C::NW / 2 : rc * kColsPerRound + gi;
       const bool active = nyq ? gi == 0 : j < C::NW / 2;
       cf x[C::EH];
 #pragma unroll
@@ -158,10 +174,14 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
             const cf wy = tw_h[(cy * k1) & (C::NH - 1)];
             v = cmul(cmul(cconj(v), wy), wx);  // conj(A) * w^(cy k1) * w^(cx k2): centre shift folded in
           }
-          if (nyq)
-            spec[static_cast<size_t>(g.rounds_c) * C::EH * kThreads + m * C::TGH + t] = v;
-          else
-            spec[(static_cast<size_t>(rc) * C::EH + m) * kThreads + tid] = v;
+          if (nyq) {
+            spec[static_cast<size_t>(g.rounds_c) * C::EH * C::NT + m * C::TGH + t] = v;
+          } else {  // the pair kernel's (round, lane) for column j
+            // element (round prc, register m, lane plane): registers 2mm, 2mm+1 of a lane are adjacent
+            // so that the pair kernel loads them with one 16-byte access
+            const int prc = j / C::CPR, plane = (j - prc * C::CPR) * C::TGH + t;
+            spec[((static_cast<size_t>(prc) * (C::EH / 2) + (m >> 1)) * C::NT + plane) * 2 + (m & 1)] = v;
+          }
         }
       }
     }
@@ -169,95 +189,172 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
 }
 
 // ============================================================================================
-// Pair kernel.  One workgroup per (query, gallery) pair; 1-D grid tiled so that the workgroups
-// resident together share a small set of query and gallery spectra (L2 / Infinity-Cache reuse).
+// Pair kernel.  One workgroup per (query, gallery) pair, looping over the channels.
+//
+// Memory-latency structure (the kernel streams ~300 KB of spectra + 1/sigma per pair and channel, far
+// more than it can keep in LDS, so everything is register-prefetched one step ahead):
+//   * the column pass is a flat sequence of "units" (channel c, column round rc); the two half-spectra
+//     of unit u+1 are loaded (16-byte loads, lane-ordered layout) before unit u is computed;
+//   * the 1/sigma slice and the Nyquist column (k2 = nw/2: one complex value per lane, staged through
+//     a small LDS buffer for the 16 lanes that consume it) of channel c+1 are loaded during channel c;
+//   * no wait is placed by hand: loads are issued a full unit early and the compiler's counted
+//     s_waitcnt sits at the first use.
+// Pair -> workgroup mapping: 1-D grid in tiles of 16 queries x 16 gallery items.  Workgroups are dealt
+// round-robin over the 8 XCDs, so workgroup w of a tile (w % 8 = XCD group) takes a 4-query x 8-gallery
+// sub-tile: the 32 workgroups sharing one L2 touch only 4 + 8 distinct spectra per channel.
 // ============================================================================================
 constexpr int kTileQ = 16, kTileG = 16;
 
 template <class C, int RR, int KW>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(C::NT, 2)
 pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
                 const unsigned char* __restrict__ pg, size_t g_item_bytes, int nq, int ng, float* __restrict__ scores,
                 long long ld, long long col0, int accumulate, float* __restrict__ maps_out,
-                const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off) {
+                const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off,
+                unsigned nyq_off_lds) {
   // ---- which pair ------------------------------------------------------------------------------
   const int tiles_g = ceil_div(ng, kTileG);
   const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
   const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
   const int tq = tile / tiles_g, tg = tile - tq * tiles_g;
-  const int qi = tq * kTileQ + within / kTileG;
-  const int gi_item = tg * kTileG + within % kTileG;
+  const int xcd = within & 7, slot = within >> 3;  // 8 XCD groups x 32 slots
+  const int qi = tq * kTileQ + 4 * (xcd >> 1) + (slot >> 3);
+  const int gi_item = tg * kTileG + 8 * (xcd & 1) + (slot & 7);
   if (qi >= nq || gi_item >= ng) return;  // uniform per workgroup
 
   unsigned char* lds = dyn_lds();
   float* red = reinterpret_cast<float*>(lds);
   cf* R = reinterpret_cast<cf*>(lds + r_off);
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
+  cf* nyq = reinterpret_cast<cf*>(lds + nyq_off_lds);  // [0, NH): gallery column nw/2, [NH, 2NH): query's
   const int tid = static_cast<int>(threadIdx.x);
-  constexpr int NV = C::PPW * KW * 2;  // accumulators per lane and row round
+  constexpr int NV = C::PPW * KW * 2;       // accumulators per lane and row round
+  constexpr int RC = C::RC;                 // column rounds per channel
+  constexpr int H2 = C::EH / 2;             // 16-byte loads per operand and unit
+  constexpr int NYQ = (2 * C::NH + C::NT - 1) / C::NT;  // Nyquist values prefetched per lane
 
-  const cf* qspec = reinterpret_cast<const cf*>(pq + static_cast<size_t>(qi) * q_item_bytes);
-  const cf* gspec = reinterpret_cast<const cf*>(pg + static_cast<size_t>(gi_item) * g_item_bytes);
-  const float* ginv = reinterpret_cast<const float*>(pg + static_cast<size_t>(gi_item) * g_item_bytes +
-                                                     sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan);
+  const unsigned char* q_item = pq + static_cast<size_t>(qi) * q_item_bytes;
+  const unsigned char* g_item = pg + static_cast<size_t>(gi_item) * g_item_bytes;
+  const cf* qspec = reinterpret_cast<const cf*>(q_item);
+  const cf* gspec = reinterpret_cast<const cf*>(g_item);
+  const float* ginv = reinterpret_cast<const float*>(g_item + sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan);
+  const size_t nyq_off = static_cast<size_t>(RC) * C::EH * C::NT;
+  const int last_c = g.channels - 1;
 
-  const int gc = tid / C::TGH, tc = tid - gc * C::TGH;  // column-pass group / lane in group
-  const int gr = tid / C::TGW, tr = tid - gr * C::TGW;  // row-pass group / lane in group
-  cf twc[C::EH], twr[C::EW];
-  load_twiddles<C::EH, C::TGH, +1>(twc, tw_h, tc);
-  load_twiddles<C::EW, C::TGW, +1>(twr, tw_w, tr);
-  cf* cbuf = xbuf + gc * GroupFftLds<C::EH, C::TGH>::kGroupElems;
-  cf* rbuf = xbuf + gr * GroupFftLds<C::EW, C::TGW>::kGroupElems;
+  const int tid0 = tid;
+  // inverse twiddle tables w^(+k) in LDS (read at use: keeps 2*(EH+EW) VGPRs free for the prefetch)
+  cf* twt_h = nyq + 2 * C::NH;
+  cf* twt_w = twt_h + C::NH;
+  for (int k = tid; k < C::NH; k += C::NT) twt_h[k] = cconj(tw_h[k]);
+  for (int k = tid; k < C::NW; k += C::NT) twt_w[k] = cconj(tw_w[k]);
 
   float acc[RR][NV];
 #pragma unroll
   for (int r = 0; r < RR; ++r)
 #pragma unroll
     for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
-
   const int pairs = g.r_rows / 2;
-  const size_t nyq_off = static_cast<size_t>(g.rounds_c) * C::EH * kThreads;
+
+  // ---- prefetch state --------------------------------------------------------------------------
+  float4 nxt[2 * H2];  // next unit: H2 x (2 complex of G), H2 x (2 complex of Q)
+  float4 inv_nxt[RR][NV / 4];
+  cf nyq_nxt[NYQ];
+  auto issue_unit = [&](int c, int rc) {
+    c = c > last_c ? last_c : c;  // the one-past-the-end prefetch re-reads the last channel (never used)
+    const float4* gs4 = reinterpret_cast<const float4*>(gspec + static_cast<size_t>(c) * g.spec_per_chan);
+    const float4* qs4 = reinterpret_cast<const float4*>(qspec + static_cast<size_t>(c) * g.spec_per_chan);
+#pragma unroll
+    for (int mm = 0; mm < H2; ++mm) {
+      const size_t idx = (static_cast<size_t>(rc) * H2 + mm) * C::NT + tid;
+      nxt[mm] = gs4[idx];
+      nxt[H2 + mm] = qs4[idx];
+    }
+  };
+  auto issue_inv = [&](int c) {
+    c = c > last_c ? last_c : c;
+    const float4* inv4 = reinterpret_cast<const float4*>(ginv + static_cast<size_t>(c) * g.inv_per_chan);
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+      for (int i = 0; i < NV / 4; ++i)
+        inv_nxt[rr][i] = rr < g.rounds_r ? inv4[(rr * (NV / 4) + i) * C::NT + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto issue_nyq = [&](int c) {
+    c = c > last_c ? last_c : c;
+    const cf* gs = gspec + static_cast<size_t>(c) * g.spec_per_chan + nyq_off;
+    const cf* qs = qspec + static_cast<size_t>(c) * g.spec_per_chan + nyq_off;
+#pragma unroll
+    for (int i = 0; i < NYQ; ++i) {
+      const int k = tid + i * C::NT;
+      nyq_nxt[i] = k < C::NH ? gs[k] : (k < 2 * C::NH ? qs[k - C::NH] : cmake(0.f, 0.f));
+    }
+  };
+  auto store_nyq = [&]() {
+#pragma unroll
+    for (int i = 0; i < NYQ; ++i) {
+      const int k = tid + i * C::NT;
+      if (k < 2 * C::NH) nyq[k] = nyq_nxt[i];
+    }
+  };
+
+  issue_nyq(0);
+  issue_unit(0, 0);
+  store_nyq();
+  __syncthreads();
 
   for (int c = 0; c < g.channels; ++c) {
-    const cf* qs = qspec + static_cast<size_t>(c) * g.spec_per_chan;
-    const cf* gs = gspec + static_cast<size_t>(c) * g.spec_per_chan;
+    // lane coordinates, re-derived from an opaque copy of the lane id every channel (see spr::opaque)
+    const int tidv = opaque(tid0);
+    const int gc = tidv / C::TGH, tc = tidv - gc * C::TGH;  // column-pass group / lane in group
+    const int gr = tidv / C::TGW, tr = tidv - gr * C::TGW;  // row-pass group / lane in group
+    const LdsTwiddles twc{twt_h, tc}, twr{twt_w, tr};
+    cf* cbuf = xbuf + gc * GroupFftLds<C::EH, C::TGH>::kGroupElems;
+    cf* rbuf = xbuf + gr * GroupFftLds<C::EW, C::TGW>::kGroupElems;
     // ---- column pass: product spectrum -> inverse transforms along k1 -> R (rows < r_rows) -------
-    for (int rc = 0; rc < g.rounds_c; ++rc) {
+#pragma unroll
+    for (int rc = 0; rc < RC; ++rc) {
       const int j = rc * C::CPR + gc;
       const bool active = j < C::NW / 2;
       cf z[C::EH];
 #pragma unroll
-      for (int m = 0; m < C::EH; ++m) {
-        const size_t idx = (static_cast<size_t>(rc) * C::EH + m) * kThreads + tid;
-        z[m] = active ? cmul(gs[idx], qs[idx]) : cmake(0.0f, 0.0f);
+      for (int mm = 0; mm < H2; ++mm) {
+        const float4 a = nxt[mm], b = nxt[H2 + mm];
+        z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
+        z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
+      }
+      // the next unit's operands fly while this unit is transformed
+      if (rc + 1 < RC) issue_unit(c, rc + 1); else issue_unit(c + 1, 0);
+      if (!active) {
+#pragma unroll
+        for (int m = 0; m < C::EH; ++m) z[m] = cmake(0.0f, 0.0f);
       }
       if (j == 0) {  // pack column nw/2 into the imaginary part of column 0
 #pragma unroll
         for (int m = 0; m < C::EH; ++m) {
-          const size_t idx = nyq_off + m * C::TGH + tc;
-          const cf zn = cmul(gs[idx], qs[idx]);
+          const int k1 = tc + C::TGH * m;
+          const cf zn = cmul(nyq[k1], nyq[C::NH + k1]);
           z[m] = cmake(z[m].x - zn.y, z[m].y + zn.x);
         }
       }
-      group_fft<C::EH, C::TGH, +1>(z, tc, twc, cbuf);
+      group_fft_tw<C::EH, C::TGH, +1>(z, tc, twc, cbuf);
       if (active) {
 #pragma unroll
         for (int m = 0; m < C::EH; ++m) {
           const int n1 = tc + C::TGH * m;
-          if (n1 < g.r_rows) R[n1 * g.r_stride + j] = z[m];
+          if (n1 < g.r_rows) R[C::r_index(n1, j)] = z[m];
         }
       }
     }
     __syncthreads();
+    issue_inv(c);  // consumed after this channel's row transforms
+    issue_nyq(c + 1);
     // ---- row pass: two real rows per inverse transform along k2 -> * 1/sigma -> accumulate --------
-    const float4* inv4 = reinterpret_cast<const float4*>(ginv + static_cast<size_t>(c) * g.inv_per_chan);
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       if (rr >= g.rounds_r) break;  // uniform: RR is the variant's compile-time maximum
       int pr = rr * C::PPR + gr;
       if (pr >= pairs) pr = pairs - 1;  // duplicate work on surplus lanes; their 1/sigma slots are 0
-      const cf* Ra = R + (2 * pr) * g.r_stride;
-      const cf* Rb = Ra + g.r_stride;
+      const int na = 2 * pr, nb = na + 1;
       cf wv[C::EW];
 #pragma unroll
       for (int m = 0; m < C::EW; ++m) {
@@ -265,18 +362,15 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
         const bool upper = k > C::NW / 2;
         const int kk = upper ? C::NW - k : k;
         const int idx = kk == C::NW / 2 ? 0 : kk;
-        const cf a = Ra[idx], b = Rb[idx];
+        const cf a = R[C::r_index(na, idx)], b = R[C::r_index(nb, idx)];
         const float ay = upper ? -a.y : a.y, by = upper ? -b.y : b.y;
         cf v = cmake(a.x - by, ay + b.x);        // Ya[k] + i*Yb[k]  (conjugated mirror for k > nw/2)
         if (k == 0) v = cmake(a.x, b.x);         // column 0 is real: its value sits in .x
         if (k == C::NW / 2) v = cmake(a.y, b.y);  // column nw/2 is real: packed into .y of slot 0
         wv[m] = v;
       }
-      group_fft<C::EW, C::TGW, +1>(wv, tr, twr, rbuf);
-      float4 iv[NV / 4];
-#pragma unroll
-      for (int i = 0; i < NV / 4; ++i) iv[i] = inv4[(rr * (NV / 4) + i) * kThreads + tid];
-      const float* ivf = reinterpret_cast<const float*>(iv);
+      group_fft_tw<C::EW, C::TGW, +1>(wv, tr, twr, rbuf);
+      const float* ivf = reinterpret_cast<const float*>(inv_nxt[rr]);
 #pragma unroll
       for (int pp = 0; pp < C::PPW; ++pp) {
 #pragma unroll
@@ -295,6 +389,7 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
         }
       }
     }
+    store_nyq();      // channel c+1's Nyquist column, consumed after the barrier
     __syncthreads();  // R is rewritten by the next channel
   }
 
@@ -305,7 +400,7 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   for (int r = 0; r < RR; ++r)
 #pragma unroll
     for (int e = 0; e < NV; ++e) best = fmaxf(best, acc[r][e]);
-  best = block_max(best, red);
+  best = block_max<C::NT>(best, red);
   if (tid == 0 && scores) {
     const float s = best / static_cast<float>(g.channels);
     float* dst = scores + static_cast<size_t>(qi) * ld + col0 + gi_item;
@@ -330,27 +425,28 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
   l.f_stride = C::NW / 2 + 1;
   const size_t f_bytes = sizeof(cf) * static_cast<size_t>(2 * ((h + 1) / 2)) * l.f_stride;
   l.xbuf_off = align_up(l.f_off + f_bytes, 16);
-  const size_t fft_total = l.xbuf_off + sizeof(cf) * C::XBUF;
+  const size_t fft_total = l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads);
   const size_t sat_total = is_query ? 0 : l.f_off + sizeof(double) * (h + 1) * (w + 1);
   l.total = fft_total > sat_total ? fft_total : sat_total;
   return l;
 }
 
 struct PairFftLds {
-  size_t r_off, xbuf_off, total;
+  size_t r_off, xbuf_off, nyq_off, total;
 };
 template <class C>
 PairFftLds pair_fft_lds(const NccGeom& g) {
   PairFftLds l;
   l.r_off = 64;
-  l.xbuf_off = align_up(l.r_off + sizeof(cf) * static_cast<size_t>(g.r_rows) * g.r_stride, 16);
-  l.total = l.xbuf_off + sizeof(cf) * C::XBUF;
+  l.xbuf_off = align_up(l.r_off + sizeof(cf) * static_cast<size_t>(g.r_rows) * C::COLS, 16);
+  l.nyq_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(C::NT), 16);
+  l.total = l.nyq_off + sizeof(cf) * (2 * C::NH + C::NH + C::NW);  // Nyquist columns + inverse twiddle tables
   return l;
 }
 
 // One entry per instantiated (nh, nw) grid.
 struct FftEntry {
-  int nh, nw, eh, tgh, ew, tgw;
+  int nh, nw, eh, tgh, ew, tgw, nt;
   int rr_tight, kw_tight, rr_loose, kw_loose;
   size_t (*prep_lds_total)(const NccGeom&, bool);
   size_t (*pair_lds_total)(const NccGeom&);
@@ -391,11 +487,12 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
-                     dim3(kThreads), l.total, stream, g, static_cast<const unsigned char*>(pq),
+                     dim3(C::NT), l.total, stream, g, static_cast<const unsigned char*>(pq),
                      prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
                      prepared_gallery_item_bytes(g, SPR_NCC_FFT), static_cast<int>(nq), static_cast<int>(ng), scores,
                      static_cast<long long>(ld), static_cast<long long>(col0), accumulate, maps_out, tw_h, tw_w,
-                     static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off));
+                     static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off),
+                     static_cast<unsigned>(l.nyq_off));
   return check_launch("pair_fft_kernel");
 }
 
@@ -413,8 +510,8 @@ int pair_t(const NccGeom& g, bool tight, const void* pq, int64_t nq, const void*
 template <class C>
 constexpr FftEntry entry() {
   return FftEntry{C::NH,          C::NW,          C::EH,         C::TGH,       C::EW,
-                  C::TGW,         rr_tight<C>(),  C::TGW / 2,    rr_loose<C>(), C::TGW,
-                  prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C>};
+                  C::TGW,         C::NT,          rr_tight<C>(), C::TGW / 2,   rr_loose<C>(),
+                  C::TGW,         prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C>};
 }
 
 // (E, TG) factorisations: 256 = 16*16, 128 = 16*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
@@ -425,7 +522,7 @@ const FftEntry kEntries[] = {
     entry<Cfg<8, 8, 8, 8>>(),      // 64 x 64
     entry<Cfg<16, 8, 8, 8>>(),     // 128 x 64
     entry<Cfg<16, 8, 16, 8>>(),    // 128 x 128
-    entry<Cfg<16, 16, 16, 8>>(),   // 256 x 128
+    entry<Cfg<16, 16, 16, 8, 512>>(),   // 256 x 128: 8 waves per workgroup (2 per SIMD), one workgroup per CU
 };
 
 const FftEntry* find_entry(int nh, int nw) {
@@ -441,19 +538,19 @@ inline int fft_need(int img, int tpl) {
 }
 
 bool fill_geometry(NccGeom& g, const FftEntry& e) {
-  g.nh = e.nh; g.nw = e.nw; g.eh = e.eh; g.tgh = e.tgh; g.ew = e.ew; g.tgw = e.tgw;
-  const int cpr = kThreads / e.tgh, ppr = kThreads / e.tgw;
+  g.nh = e.nh; g.nw = e.nw; g.eh = e.eh; g.tgh = e.tgh; g.ew = e.ew; g.tgw = e.tgw; g.nt = e.nt;
+  const int cpr = e.nt / e.tgh, ppr = e.nt / e.tgw;
   g.rounds_c = ceil_div(e.nw / 2, cpr);
   const bool tight = g.ih <= e.nh / 2 && g.iw <= e.nw / 2;
   g.tight = tight ? 1 : 0;
   g.sh = ceil_div(g.ih, e.eh);  // kept outputs per column sub-transform (<= tgh/2 when tight)
   g.r_rows = e.eh * g.sh;
-  g.r_stride = e.nw / 2 + 4;
+  g.r_stride = e.nw / 2;
   g.rounds_r = ceil_div(g.r_rows / 2, ppr);
   g.keep_w = tight ? e.kw_tight : e.kw_loose;
   if (g.rounds_r > (tight ? e.rr_tight : e.rr_loose)) return false;
-  g.spec_per_chan = g.rounds_c * e.eh * kThreads + e.nh;
-  g.inv_per_chan = g.rounds_r * (e.ew / e.tgw) * g.keep_w * 2 * kThreads;
+  g.spec_per_chan = g.rounds_c * e.eh * e.nt + e.nh;
+  g.inv_per_chan = g.rounds_r * (e.ew / e.tgw) * g.keep_w * 2 * e.nt;
   if (g.ih * g.iw > kMaxPixPerThread * kThreads || g.th * g.tw > kMaxPixPerThread * kThreads) return false;
   if (e.prep_lds_total(g, true) > static_cast<size_t>(kLdsLimit)) return false;
   if (e.prep_lds_total(g, false) > static_cast<size_t>(kLdsLimit)) return false;

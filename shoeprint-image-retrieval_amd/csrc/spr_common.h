@@ -9,7 +9,7 @@
 
 namespace spr {
 
-constexpr int kThreads = 256;          // work-items per workgroup of every NCC kernel (4 waves)
+constexpr int kThreads = 256;          // work-items per workgroup of the prep / direct / rank kernels (4 waves)
 constexpr int kLdsLimit = 160 * 1024;  // LDS per CU on gfx950
 
 struct cf {  // complex<float>, 8-byte aligned so LDS/global accesses are single b64 ops
@@ -37,6 +37,7 @@ struct NccGeom {
   int dtype;
   // FFT method only ------------------------------------------------------------------------
   int nh, nw;          // FFT grid (rows, cols); nh = eh*tgh, nw = ew*tgw
+  int nt;              // work-items per workgroup of the pair kernel (prepared layouts are tiled by it)
   int eh, tgh, ew, tgw;
   int tight;           // 1: ih <= nh/2 and iw <= nw/2 (the pruned kernel variant), 0: general variant
   int rounds_c;        // column-pass rounds of (kThreads/tgh) columns covering nw/2 columns
@@ -99,6 +100,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   for (int w = 0; w < kThreads / 64; ++w) s += scratch[w];
   return s;
 }
+template <int NT = kThreads>
 __device__ __forceinline__ float block_max(float v, float* scratch) {
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
   const int tid = static_cast<int>(threadIdx.x);
@@ -106,7 +108,7 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   if ((tid & 63) == 0) scratch[tid >> 6] = v;
   __syncthreads();
   float s = scratch[0];
-  for (int w = 1; w < kThreads / 64; ++w) s = fmaxf(s, scratch[w]);
+  for (int w = 1; w < NT / 64; ++w) s = fmaxf(s, scratch[w]);
   return s;
 }
 

@@ -31,6 +31,14 @@ __device__ __forceinline__ double shfl_xor(double v, int mask) { return __shfl_x
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, kWave); }
 __device__ __forceinline__ int shfl(int v, int src) { return __shfl(v, src, kWave); }
 
+// Make a lane-constant value opaque to the optimiser at this point: address arithmetic derived from it
+// cannot be hoisted out of the enclosing loop (loop-invariant hoisting of ~100 LDS/global addresses costs
+// more VGPRs than recomputing them).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // D = A(16x4) * B(4x16) + C, exact f32 (k-ordered fmaf chain).  Lane l supplies
 // A[l&15][l>>4] and B[l>>4][l&15]; it owns D[(l>>4)*4 + j][l&15], j = 0..3.
 __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {

@@ -38,6 +38,8 @@ inline double shfl_xor(double v, int mask) { return exchange(v, lane_id() ^ mask
 inline float shfl(float v, int src) { return exchange(v, src); }
 inline int shfl(int v, int src) { return exchange(v, src); }
 
+inline int opaque(int v) { return v; }
+
 // Emulated MFMA: every lane publishes its A/B element, then computes its own D entries as the
 // k-ordered fmaf chain the hardware produces.
 inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
