@@ -19,14 +19,15 @@
 
 namespace spr {
 
-__device__ __forceinline__ cf cmake(float x, float y) { cf r; r.x = x; r.y = y; return r; }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return cmake(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return cmake(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cf cconj(cf a) { return cmake(a.x, -a.y); }
+__device__ __forceinline__ cf cmake(float x, float y) { return cf{x, y}; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 // multiply by +i / -i
-__device__ __forceinline__ cf cmul_i(cf a) { return cmake(-a.y, a.x); }
-__device__ __forceinline__ cf cmul_mi(cf a) { return cmake(a.y, -a.x); }
+__device__ __forceinline__ cf cmul_i(cf a) { return cf{-a.y, a.x}; }
+__device__ __forceinline__ cf cmul_mi(cf a) { return cf{a.y, -a.x}; }
+// (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (i*b): one packed multiply + one packed fma
+__device__ __forceinline__ cf cmul(cf a, cf b) { return a.xx * b + a.yy * cmul_i(b); }
+__device__ __forceinline__ cf cconj(cf a) { return cf{a.x, -a.y}; }
 
 // cos / sin of 2*pi*k/48, k = 0..47 (covers the 16th and 24th roots of unity), rounded from
 // double precision.
@@ -68,7 +69,7 @@ __device__ __forceinline__ cf rot(cf a) {
   } else {
     constexpr float c = kCos48[k * (48 / N)];
     constexpr float s = DIR > 0 ? kSin48[k * (48 / N)] : -kSin48[k * (48 / N)];
-    return cmake(a.x * c - a.y * s, a.x * s + a.y * c);
+    return a * c + cmul_i(a) * s;
   }
 }
 
@@ -93,8 +94,8 @@ struct Dft<3, DIR> {
     // X0 = a+b+c; X1 = a + w b + w^2 c; X2 = a + w^2 b + w c, w = exp(DIR*2pi*i/3)
     const cf a = x[0], s = cadd(x[1], x[2]), d = csub(x[1], x[2]);
     constexpr float h = 0.86602540378443860f;  // sin(2*pi/3)
-    const cf m = cmake(a.x - 0.5f * s.x, a.y - 0.5f * s.y);
-    const cf j = DIR > 0 ? cmake(-h * d.y, h * d.x) : cmake(h * d.y, -h * d.x);  // ±i*h*d
+    const cf m = a - 0.5f * s;
+    const cf j = DIR > 0 ? cmul_i(d) * h : cmul_mi(d) * h;  // ±i*h*d
     x[0] = cadd(a, s);
     x[1] = cadd(m, j);
     x[2] = csub(m, j);
@@ -184,12 +185,13 @@ struct RegTwiddles {
   cf w[E];
   __device__ __forceinline__ cf get(int p) const { return w[p]; }
 };
-// ... or a table in LDS holding w_N^(DIR*k), k = 0..N-1, read at use (saves 2E VGPRs per lane; lanes of a
-// group read entries t*p: a small strided access pattern, one ds_read_b64 per butterfly output).
+// ... or a table in LDS laid out [p][t] = w_N^(DIR*t*p) (E rows of TG entries), read at use: saves 2E VGPRs
+// per lane, and the TG lanes of a group read TG consecutive entries (conflict-free, all groups broadcast).
+template <int TG>
 struct LdsTwiddles {
   const cf* table;
   int t;
-  __device__ __forceinline__ cf get(int p) const { return table[t * p]; }
+  __device__ __forceinline__ cf get(int p) const { return table[p * TG + t]; }
 };
 
 template <int E, int TG, int DIR, class Tw>

@@ -43,13 +43,12 @@ struct Cfg {
                ? GroupFftLds<EH, TGH>::block_elems(threads)
                : GroupFftLds<EW, TGW>::block_elems(threads);
   }
-  // Physical position of R[n1][j]: rows of COLS complex values, column XOR-swizzled by the row so that
-  // (a) the 16 lanes of a column transform writing rows t+16m of one column and (b) the four 8-lane row
-  // groups of a 32-lane half reading 8 consecutive columns of four different row pairs are conflict-free.
-  static __device__ __forceinline__ int r_index(int n1, int j) {
-    const int swz = ((n1 & 15) ^ (((n1 >> 1) & 3) << 3)) & (COLS - 1);
-    return n1 * COLS + (j ^ swz);
-  }
+  // The intermediate image is stored TRANSPOSED: RT[j][n1], column j of the half spectrum, row n1, with a
+  // row stride == 8 (mod 32) complex values.  Column transforms then write 16 consecutive values per
+  // 16-lane slice with compile-time offsets, and a row-pair lane reads (row 2pr, row 2pr+1) of one column
+  // as a single 16-byte access; with that stride the four 8-lane groups of every ds_read_b128 lane group
+  // cover all 64 banks exactly once.
+  static constexpr int rt_stride(int r_rows) { return r_rows + ((8 - r_rows % 32) + 32) % 32; }
 };
 
 // ============================================================================================
@@ -245,8 +244,8 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   // inverse twiddle tables w^(+k) in LDS (read at use: keeps 2*(EH+EW) VGPRs free for the prefetch)
   cf* twt_h = nyq + 2 * C::NH;
   cf* twt_w = twt_h + C::NH;
-  for (int k = tid; k < C::NH; k += C::NT) twt_h[k] = cconj(tw_h[k]);
-  for (int k = tid; k < C::NW; k += C::NT) twt_w[k] = cconj(tw_w[k]);
+  for (int k = tid; k < C::NH; k += C::NT) twt_h[k] = cconj(tw_h[(k / C::TGH) * (k % C::TGH)]);  // [p][t]
+  for (int k = tid; k < C::NW; k += C::NT) twt_w[k] = cconj(tw_w[(k / C::TGW) * (k % C::TGW)]);
 
   float acc[RR][NV];
 #pragma unroll
@@ -254,6 +253,8 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
 #pragma unroll
     for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
   const int pairs = g.r_rows / 2;
+  const int rs = g.r_stride;  // row stride of the transposed image RT[j][n1]
+  const int m_keep = g.r_rows / C::TGH;  // registers of a column transform whose rows are kept (r_rows = EH*sh)
 
   // ---- prefetch state --------------------------------------------------------------------------
   float4 nxt[2 * H2];  // next unit: H2 x (2 complex of G), H2 x (2 complex of Q)
@@ -307,7 +308,8 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
     const int tidv = opaque(tid0);
     const int gc = tidv / C::TGH, tc = tidv - gc * C::TGH;  // column-pass group / lane in group
     const int gr = tidv / C::TGW, tr = tidv - gr * C::TGW;  // row-pass group / lane in group
-    const LdsTwiddles twc{twt_h, tc}, twr{twt_w, tr};
+    const LdsTwiddles<C::TGH> twc{twt_h, tc};
+    const LdsTwiddles<C::TGW> twr{twt_w, tr};
     cf* cbuf = xbuf + gc * GroupFftLds<C::EH, C::TGH>::kGroupElems;
     cf* rbuf = xbuf + gr * GroupFftLds<C::EW, C::TGW>::kGroupElems;
     // ---- column pass: product spectrum -> inverse transforms along k1 -> R (rows < r_rows) -------
@@ -324,9 +326,11 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
       }
       // the next unit's operands fly while this unit is transformed
       if (rc + 1 < RC) issue_unit(c, rc + 1); else issue_unit(c + 1, 0);
-      if (!active) {
+      if constexpr (RC * C::CPR != C::NW / 2) {  // surplus groups of the last round transform zeros
+        if (!active) {
 #pragma unroll
-        for (int m = 0; m < C::EH; ++m) z[m] = cmake(0.0f, 0.0f);
+          for (int m = 0; m < C::EH; ++m) z[m] = cmake(0.0f, 0.0f);
+        }
       }
       if (j == 0) {  // pack column nw/2 into the imaginary part of column 0
 #pragma unroll
@@ -338,10 +342,10 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
       }
       group_fft_tw<C::EH, C::TGH, +1>(z, tc, twc, cbuf);
       if (active) {
+        cf* col = R + j * rs + tc;
 #pragma unroll
         for (int m = 0; m < C::EH; ++m) {
-          const int n1 = tc + C::TGH * m;
-          if (n1 < g.r_rows) R[C::r_index(n1, j)] = z[m];
+          if (m < m_keep) col[C::TGH * m] = z[m];  // row tc + TGH*m < r_rows  <=>  m < r_rows/TGH: uniform
         }
       }
     }
@@ -354,20 +358,30 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
       if (rr >= g.rounds_r) break;  // uniform: RR is the variant's compile-time maximum
       int pr = rr * C::PPR + gr;
       if (pr >= pairs) pr = pairs - 1;  // duplicate work on surplus lanes; their 1/sigma slots are 0
-      const int na = 2 * pr, nb = na + 1;
+      // W[k] = Ya[k] + i*Yb[k] for k = tr + TGW*m, built from the stored half spectrum (columns 0..nw/2-1;
+      // column nw/2 rides in the imaginary part of column 0).  Which form applies is a compile-time
+      // property of the register index m, except for lane tr == 0 of the two registers holding k = 0, nw/2.
+      const cf* direct = R + tr * rs + 2 * pr;                // column k            (k < nw/2)
+      const cf* mirror = R + (C::TGW - tr) * rs + 2 * pr;     // column nw - k       (k > nw/2), from m = EW-1 down
       cf wv[C::EW];
 #pragma unroll
       for (int m = 0; m < C::EW; ++m) {
-        const int k = tr + C::TGW * m;
-        const bool upper = k > C::NW / 2;
-        const int kk = upper ? C::NW - k : k;
-        const int idx = kk == C::NW / 2 ? 0 : kk;
-        const cf a = R[C::r_index(na, idx)], b = R[C::r_index(nb, idx)];
-        const float ay = upper ? -a.y : a.y, by = upper ? -b.y : b.y;
-        cf v = cmake(a.x - by, ay + b.x);        // Ya[k] + i*Yb[k]  (conjugated mirror for k > nw/2)
-        if (k == 0) v = cmake(a.x, b.x);         // column 0 is real: its value sits in .x
-        if (k == C::NW / 2) v = cmake(a.y, b.y);  // column nw/2 is real: packed into .y of slot 0
-        wv[m] = v;
+        if constexpr (true) {
+          if (m < C::EW / 2) {
+            const float4 ab = *reinterpret_cast<const float4*>(direct + m * C::TGW * rs);
+            cf v = cmake(ab.x - ab.w, ab.y + ab.z);  // Ya + i*Yb
+            if (m == 0) v = tr == 0 ? cmake(ab.x, ab.z) : v;  // k = 0: both columns real, values in .x
+            wv[m] = v;
+          } else if (m == C::EW / 2) {
+            // k = nw/2 + tr: lane 0 takes the packed Nyquist column (.y of column 0), the others column nw/2 - tr
+            const cf* src = tr == 0 ? R + 2 * pr : mirror + (C::EW - 1 - m) * C::TGW * rs;
+            const float4 ab = *reinterpret_cast<const float4*>(src);
+            wv[m] = tr == 0 ? cmake(ab.y, ab.w) : cmake(ab.x + ab.w, ab.z - ab.y);
+          } else {
+            const float4 ab = *reinterpret_cast<const float4*>(mirror + (C::EW - 1 - m) * C::TGW * rs);
+            wv[m] = cmake(ab.x + ab.w, ab.z - ab.y);  // conj(Ya) + i*conj(Yb)
+          }
+        }
       }
       group_fft_tw<C::EW, C::TGW, +1>(wv, tr, twr, rbuf);
       const float* ivf = reinterpret_cast<const float*>(inv_nxt[rr]);
@@ -438,7 +452,7 @@ template <class C>
 PairFftLds pair_fft_lds(const NccGeom& g) {
   PairFftLds l;
   l.r_off = 64;
-  l.xbuf_off = align_up(l.r_off + sizeof(cf) * static_cast<size_t>(g.r_rows) * C::COLS, 16);
+  l.xbuf_off = align_up(l.r_off + sizeof(cf) * static_cast<size_t>(C::COLS) * g.r_stride, 16);
   l.nyq_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(C::NT), 16);
   l.total = l.nyq_off + sizeof(cf) * (2 * C::NH + C::NH + C::NW);  // Nyquist columns + inverse twiddle tables
   return l;
@@ -545,7 +559,7 @@ bool fill_geometry(NccGeom& g, const FftEntry& e) {
   g.tight = tight ? 1 : 0;
   g.sh = ceil_div(g.ih, e.eh);  // kept outputs per column sub-transform (<= tgh/2 when tight)
   g.r_rows = e.eh * g.sh;
-  g.r_stride = e.nw / 2;
+  g.r_stride = g.r_rows + ((8 - g.r_rows % 32) + 32) % 32;  // Cfg::rt_stride
   g.rounds_r = ceil_div(g.r_rows / 2, ppr);
   g.keep_w = tight ? e.kw_tight : e.kw_loose;
   if (g.rounds_r > (tight ? e.rr_tight : e.rr_loose)) return false;

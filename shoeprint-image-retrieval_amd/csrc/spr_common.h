@@ -12,9 +12,10 @@ namespace spr {
 constexpr int kThreads = 256;          // work-items per workgroup of the prep / direct / rank kernels (4 waves)
 constexpr int kLdsLimit = 160 * 1024;  // LDS per CU on gfx950
 
-struct cf {  // complex<float>, 8-byte aligned so LDS/global accesses are single b64 ops
-  float x, y;
-};
+// complex<float> as a 2-wide vector: 8-byte aligned (single b64 LDS/global accesses) and complex
+// add / sub / multiply lower to packed fp32 VALU (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32), which
+// issue at the scalar rate on gfx950: half the instructions at the low occupancy these kernels run at.
+typedef float cf __attribute__((ext_vector_type(2)));
 static_assert(sizeof(cf) == 8, "cf must be 8 bytes");
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -43,7 +44,7 @@ struct NccGeom {
   int rounds_c;        // column-pass rounds of (kThreads/tgh) columns covering nw/2 columns
   int sh;              // kept outputs per column sub-transform: rows 0 .. eh*sh-1 cover ih
   int r_rows;          // eh*sh rows of the intermediate LDS image
-  int r_stride;        // its row stride in complex elements
+  int r_stride;        // row stride (complex elements) of the transposed LDS image RT[column][row]
   int rounds_r;        // row-pass rounds of (kThreads/tgw) row pairs covering r_rows/2 pairs (r_rows is even)
   int keep_w;          // kept outputs per row sub-transform (covers iw)
   int spec_per_chan;   // complex elements of one channel's spectrum (tiled layout)
