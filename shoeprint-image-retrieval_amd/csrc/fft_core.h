@@ -26,7 +26,7 @@ __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 __device__ __forceinline__ cf cmul_i(cf a) { return cf{-a.y, a.x}; }
 __device__ __forceinline__ cf cmul_mi(cf a) { return cf{a.y, -a.x}; }
 // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (i*b): one packed multiply + one packed fma
-__device__ __forceinline__ cf cmul(cf a, cf b) { return a.xx * b + a.yy * cmul_i(b); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return pk_cmul(a, b); }
 __device__ __forceinline__ cf cconj(cf a) { return cf{a.x, -a.y}; }
 
 // cos / sin of 2*pi*k/48, k = 0..47 (covers the 16th and 24th roots of unity), rounded from
@@ -69,7 +69,7 @@ __device__ __forceinline__ cf rot(cf a) {
   } else {
     constexpr float c = kCos48[k * (48 / N)];
     constexpr float s = DIR > 0 ? kSin48[k * (48 / N)] : -kSin48[k * (48 / N)];
-    return a * c + cmul_i(a) * s;
+    return pk_rot(a, c, s);
   }
 }
 
@@ -106,9 +106,15 @@ struct Dft<3, DIR> {
 template <int N, int DIR, int K>
 struct Combine2 {
   static __device__ __forceinline__ void run(cf (&x)[N], const cf (&e)[N / 2], const cf (&o)[N / 2]) {
-    const cf t = rot<N, K, DIR>(o[K]);
-    x[K] = cadd(e[K], t);
-    x[K + N / 2] = csub(e[K], t);
+    constexpr int k = ((K % N) + N) % N;
+    if constexpr (4 * k == N) {  // twiddle = +-i: fused into the packed add (no rotate instruction)
+      x[K] = DIR > 0 ? pk_add_i(e[K], o[K]) : pk_sub_i(e[K], o[K]);
+      x[K + N / 2] = DIR > 0 ? pk_sub_i(e[K], o[K]) : pk_add_i(e[K], o[K]);
+    } else {
+      const cf t = rot<N, K, DIR>(o[K]);
+      x[K] = cadd(e[K], t);
+      x[K + N / 2] = csub(e[K], t);
+    }
     if constexpr (K + 1 < N / 2) Combine2<N, DIR, K + 1>::run(x, e, o);
   }
 };

@@ -336,8 +336,7 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
 #pragma unroll
         for (int m = 0; m < C::EH; ++m) {
           const int k1 = tc + C::TGH * m;
-          const cf zn = cmul(nyq[k1], nyq[C::NH + k1]);
-          z[m] = cmake(z[m].x - zn.y, z[m].y + zn.x);
+          z[m] = pk_add_i(z[m], cmul(nyq[k1], nyq[C::NH + k1]));
         }
       }
       group_fft_tw<C::EH, C::TGH, +1>(z, tc, twc, cbuf);
@@ -369,17 +368,17 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
         if constexpr (true) {
           if (m < C::EW / 2) {
             const float4 ab = *reinterpret_cast<const float4*>(direct + m * C::TGW * rs);
-            cf v = cmake(ab.x - ab.w, ab.y + ab.z);  // Ya + i*Yb
+            cf v = pk_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // Ya + i*Yb
             if (m == 0) v = tr == 0 ? cmake(ab.x, ab.z) : v;  // k = 0: both columns real, values in .x
             wv[m] = v;
           } else if (m == C::EW / 2) {
             // k = nw/2 + tr: lane 0 takes the packed Nyquist column (.y of column 0), the others column nw/2 - tr
             const cf* src = tr == 0 ? R + 2 * pr : mirror + (C::EW - 1 - m) * C::TGW * rs;
             const float4 ab = *reinterpret_cast<const float4*>(src);
-            wv[m] = tr == 0 ? cmake(ab.y, ab.w) : cmake(ab.x + ab.w, ab.z - ab.y);
+            wv[m] = tr == 0 ? cmake(ab.y, ab.w) : pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));
           } else {
             const float4 ab = *reinterpret_cast<const float4*>(mirror + (C::EW - 1 - m) * C::TGW * rs);
-            wv[m] = cmake(ab.x + ab.w, ab.z - ab.y);  // conj(Ya) + i*conj(Yb)
+            wv[m] = pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // conj(Ya) + i*conj(Yb)
           }
         }
       }

@@ -39,6 +39,48 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// ---- complex arithmetic on packed fp32 (a complex number = one 64-bit VGPR pair {re, im}) -----------
+// hipcc materialises i*x (swap halves, flip one sign) as v_mov + v_xor before a packed op; the VOP3P
+// operand modifiers do it for free.  op_sel / op_sel_hi pick the source half feeding the low / high
+// result, neg_lo / neg_hi negate it.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// e + i*o = (e.x - o.y, e.y + o.x)
+__device__ __forceinline__ f32x2 pk_add_i(f32x2 e, f32x2 o) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(e), "v"(o));
+  return r;
+}
+// e - i*o = (e.x + o.y, e.y - o.x)
+__device__ __forceinline__ f32x2 pk_sub_i(f32x2 e, f32x2 o) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(e), "v"(o));
+  return r;
+}
+// conj(a) + i*conj(b) = (a.x + b.y, b.x - a.y)
+__device__ __forceinline__ f32x2 pk_conj_add_i(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a * b (complex): a.xx*b, then += a.yy * (i*b)
+__device__ __forceinline__ f32x2 pk_cmul(f32x2 a, f32x2 b) {
+  f32x2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,0,0]"
+      : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+// a * (c + i*s) with wave-uniform c, s (compile-time twiddles live in SGPR pairs): a*c + (i*a)*s
+__device__ __forceinline__ f32x2 pk_rot(f32x2 a, float c, float s) {
+  const f32x2 t = a * c;
+  const f32x2 ss = {s, s};
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0] neg_hi:[0,0,0]"
+      : "=v"(r) : "v"(a), "s"(ss), "v"(t));
+  return r;
+}
+
 // D = A(16x4) * B(4x16) + C, exact f32 (k-ordered fmaf chain).  Lane l supplies
 // A[l&15][l>>4] and B[l>>4][l&15]; it owns D[(l>>4)*4 + j][l&15], j = 0..3.
 __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {

@@ -40,6 +40,19 @@ inline int shfl(int v, int src) { return exchange(v, src); }
 
 inline int opaque(int v) { return v; }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+inline f32x2 pk_add_i(f32x2 e, f32x2 o) { return f32x2{e.x - o.y, e.y + o.x}; }
+inline f32x2 pk_sub_i(f32x2 e, f32x2 o) { return f32x2{e.x + o.y, e.y - o.x}; }
+inline f32x2 pk_conj_add_i(f32x2 a, f32x2 b) { return f32x2{a.x + b.y, b.x - a.y}; }
+inline f32x2 pk_cmul(f32x2 a, f32x2 b) {
+  const f32x2 t = {a.x * b.x, a.x * b.y};
+  return f32x2{std::fmaf(a.y, -b.y, t.x), std::fmaf(a.y, b.x, t.y)};
+}
+inline f32x2 pk_rot(f32x2 a, float c, float s) {
+  const f32x2 t = {a.x * c, a.y * c};
+  return f32x2{std::fmaf(-a.y, s, t.x), std::fmaf(a.x, s, t.y)};
+}
+
 // Emulated MFMA: every lane publishes its A/B element, then computes its own D entries as the
 // k-ordered fmaf chain the hardware produces.
 inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
