@@ -257,18 +257,18 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   const int m_keep = g.r_rows / C::TGH;  // registers of a column transform whose rows are kept (r_rows = EH*sh)
 
   // ---- prefetch state --------------------------------------------------------------------------
-  float4 nxt[2 * H2];  // next unit: H2 x (2 complex of G), H2 x (2 complex of Q)
+  float4 nxt[RC][2 * H2];  // one buffer per column round: H2 x (2 complex of G), H2 x (2 complex of Q)
   float4 inv_nxt[RR][NV / 4];
   cf nyq_nxt[NYQ];
-  auto issue_unit = [&](int c, int rc) {
+  auto issue_unit = [&](int c, int rc, float4 (&buf)[2 * H2]) {
     c = c > last_c ? last_c : c;  // the one-past-the-end prefetch re-reads the last channel (never used)
     const float4* gs4 = reinterpret_cast<const float4*>(gspec + static_cast<size_t>(c) * g.spec_per_chan);
     const float4* qs4 = reinterpret_cast<const float4*>(qspec + static_cast<size_t>(c) * g.spec_per_chan);
 #pragma unroll
     for (int mm = 0; mm < H2; ++mm) {
       const size_t idx = (static_cast<size_t>(rc) * H2 + mm) * C::NT + tid;
-      nxt[mm] = gs4[idx];
-      nxt[H2 + mm] = qs4[idx];
+      buf[mm] = gs4[idx];
+      buf[H2 + mm] = qs4[idx];
     }
   };
   auto issue_inv = [&](int c) {
@@ -299,7 +299,8 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   };
 
   issue_nyq(0);
-  issue_unit(0, 0);
+#pragma unroll
+  for (int rc = 0; rc < RC; ++rc) issue_unit(0, rc, nxt[rc]);
   store_nyq();
   __syncthreads();
 
@@ -320,12 +321,12 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
       cf z[C::EH];
 #pragma unroll
       for (int mm = 0; mm < H2; ++mm) {
-        const float4 a = nxt[mm], b = nxt[H2 + mm];
+        const float4 a = nxt[rc][mm], b = nxt[rc][H2 + mm];
         z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
         z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
       }
-      // the next unit's operands fly while this unit is transformed
-      if (rc + 1 < RC) issue_unit(c, rc + 1); else issue_unit(c + 1, 0);
+      // this round's operands of the NEXT channel start flying now: a full channel (RC units) of lead
+      issue_unit(c + 1, rc, nxt[rc]);
       if constexpr (RC * C::CPR != C::NW / 2) {  // surplus groups of the last round transform zeros
         if (!active) {
 #pragma unroll

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Time the NCC pair kernel alone for one or more builds of the library (A/B in one process, interleaved
+rounds — cdna guide rule 24).  usage: time_pair.py [lib.so ...]   (default: the in-tree build)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from shoeprint_image_retrieval_amd import _lib, synth
+from shoeprint_image_retrieval_amd.similarity import NccScorer
+C, H, W = int(os.environ.get("TP_C", 256)), int(os.environ.get("TP_H", 128)), int(os.environ.get("TP_W", 64))
+NQ, NG = int(os.environ.get("TP_Q", 32)), int(os.environ.get("TP_G", 512))
+paths = sys.argv[1:] or [None]
+scorers = [NccScorer(method="fft", library=_lib.load_library(p)) for p in paths]
+sc0 = scorers[0]; dev = sc0.dev; lib = sc0.lib
+g = dev.empty((NG, C, H, W), np.float32); q = dev.empty((NQ, C, H, W), np.float32)
+m = dev.to_device(synth.default_matches(NQ, NG))
+lib.check(lib.spr_synth_gallery(dev.ptr(g), 0, NG, C, H, W, 1234, dev.stream()))
+lib.check(lib.spr_synth_queries(dev.ptr(q), 0, NQ, dev.ptr(m), C, H, W, 1234, 3, 3, 2, dev.stream()))
+state = []
+for sc in scorers:
+    plan = sc.plan(C, (H, W), (H, W))
+    pq = sc.prepare_queries(plan, q); pg = sc.prepare_gallery(plan, g)
+    scores = dev.zeros((NQ, NG), np.float32)
+    state.append((sc, plan, pq, pg, scores))
+res = {i: [] for i in range(len(scorers))}
+for rnd in range(4):
+    for i, (sc, plan, pq, pg, scores) in enumerate(state):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); sc.score_prepared(plan, pq, NQ, pg, NG, scores, NG, 0); e1.record(); torch.cuda.synchronize()
+        if rnd: res[i].append(e0.elapsed_time(e1))
+ref = dev.to_host(state[0][4])
+for i, p in enumerate(paths):
+    ms = np.array(res[i]); d = np.abs(dev.to_host(state[i][4]) - ref).max()
+    print(f"{os.path.basename(p or 'in-tree'):28s} pair kernel min {ms.min():8.2f} ms  med {np.median(ms):8.2f} ms  -> {NQ*NG/ms.min()*1e3:9.0f} pairs/s   max|d vs first| {d:.2e}")
