@@ -171,6 +171,16 @@ def main():
         "note": "fp32 FFT butterflies run on the vector ALU; FP32 vector peak = FP32 MFMA peak = 157.3 TFLOP/s",
     }
 
+    # HBM-side traffic of the pair kernel per launch: from the committed rocprofv3 --pmc passes of THIS
+    # command (profiles/, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), default workload only.
+    try:
+        if (nq, ng_local, world, method) == (Q_PER_JOB, G_PER_GPU, 1, 1):
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")))
+            roofline["traffic"] = prof["pair_fft_kernel traffic per launch"]["hbm_bytes_per_launch"]
+            roofline["traffic_unit"] = "bytes per launch (memory-side L2 requests incl. Infinity-Cache hits)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     out = {
         "metric": "query x gallery NCC pairs/sec", "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
