@@ -12,6 +12,7 @@
  *   similarity.py:355-367  score matrix, floor 0, max over variants -> spr_ncc_score
  *   similarity.py:378-386  _get_rank            -> spr_rank_true_match
  *   network.py:185-244     truncated VGG16 forward -> spr_vgg16_* (see below)
+ *   network.py:60-71       ToTensor / repeat(3) / Normalize -> fused into the first conv layer
  *
  * (INTEGRATION.md shows the binding stubs.)
  *
@@ -134,6 +135,47 @@ int spr_rank_true_match(const float* scores, int64_t ld, int64_t n_queries, int6
 int spr_rank_count_greater(const float* scores, int64_t ld, int64_t n_queries, int64_t n_local,
                            int64_t global_col0, const float* match_scores, const int32_t* match,
                            int32_t* counts, spr_stream_t stream);
+
+/* ------------------------------------------------------------------ feature extractor (VGG16)
+ *
+ * network.py:125-134, 185-186: torchvision vgg16().features truncated to its first `block` children
+ * (index -> layer: 0 conv1_1 1 ReLU 2 conv1_2 3 ReLU 4 pool | 5 conv2_1 6 R 7 conv2_2 8 R 9 pool |
+ * 10 conv3_1 11 R 12 conv3_2 13 R 14 conv3_3 15 R 16 pool | 17 conv4_1 .. 22 R 23 pool | 24 conv5_1 .. 29 R
+ * 30 pool), convolutions 3x3 / stride 1 / zero pad 1 / bias, pools 2x2 stride 2 (floor).  Every
+ * convolution runs as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32
+ * fma chains) with bias, ReLU and the following pool fused into its epilogue.
+ *
+ * Pre-processing fused into the first layer (network.py:60-71, 127-130): x'_c = (pixel/255 - mean_c)/std_c
+ * with the zero padding applied AFTER normalisation.  `mean`/`inv_std` are the three per-channel values in
+ * [0,1] units (VGG16: mean (0.48235, 0.45882, 0.40784), std 1/255 each).  CLAHE (network.py:197-208) is
+ * applied by the caller before this entry point.
+ */
+typedef struct spr_vgg16_plan spr_vgg16_plan;
+
+int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out);
+void spr_vgg16_plan_destroy(spr_vgg16_plan* plan);
+/* Number of convolution layers inside features[:block] and their (cin, cout). */
+int spr_vgg16_num_convs(const spr_vgg16_plan* plan);
+int spr_vgg16_conv_shape(const spr_vgg16_plan* plan, int32_t conv_index, int32_t* cin, int32_t* cout);
+/* Output shape [channels, h, w] for an in_h x in_w image. */
+int spr_vgg16_output_shape(const spr_vgg16_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels,
+                           int32_t* out_h, int32_t* out_w);
+
+/* Re-pack torch-layout parameters into the kernels' layout.  weights[i]: device float32
+ * [cout_i, cin_i, 3, 3]; biases[i]: device float32 [cout_i] (host arrays of device pointers, one per
+ * convolution).  packed: device buffer of spr_vgg16_packed_bytes(). */
+size_t spr_vgg16_packed_bytes(const spr_vgg16_plan* plan);
+int spr_vgg16_pack_weights(spr_vgg16_plan* plan, const float* const* weights, const float* const* biases,
+                           void* packed, spr_stream_t stream);
+
+/* Forward pass of n images.  images: device uint8, [n, in_h, in_w] (in_channels = 1: the grey value is
+ * repeated over the 3 input planes, network.py:67) or [n, in_h, in_w, 3] (in_channels = 3, RGB).
+ * workspace: device buffer of spr_vgg16_workspace_bytes(); out: device float32 [n, C, h, w] (NCHW, the
+ * layout Model.get_feature_maps returns per image, network.py:241-244). */
+size_t spr_vgg16_workspace_bytes(const spr_vgg16_plan* plan, int64_t n, int32_t in_h, int32_t in_w);
+int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                      int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                      void* workspace, float* out, spr_stream_t stream);
 
 /* ------------------------------------------------------------------ synthetic data
  * Bench/test support: the device twin of shoeprint_image_retrieval_amd/synth.py (bit-identical

@@ -55,6 +55,16 @@ SIGNATURES = {
     "spr_ncc_maps": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "spr_rank_true_match": (C.c_int, [_VP, _I64, _I64, _I64, _VP, _VP, _VP]),
     "spr_rank_count_greater": (C.c_int, [_VP, _I64, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
+    "spr_vgg16_plan_create": (C.c_int, [_I32, C.POINTER(_VP)]),
+    "spr_vgg16_plan_destroy": (None, [_VP]),
+    "spr_vgg16_num_convs": (C.c_int, [_VP]),
+    "spr_vgg16_conv_shape": (C.c_int, [_VP, _I32, C.POINTER(_I32), C.POINTER(_I32)]),
+    "spr_vgg16_output_shape": (C.c_int, [_VP, _I32, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "spr_vgg16_packed_bytes": (_SZ, [_VP]),
+    "spr_vgg16_pack_weights": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), _VP, _VP]),
+    "spr_vgg16_workspace_bytes": (_SZ, [_VP, _I64, _I32, _I32]),
+    "spr_vgg16_forward": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    _VP, _VP, _VP, _VP]),
     "spr_synth_gallery": (C.c_int, [_VP, _I64, _I64, _I32, _I32, _I32, C.c_uint64, _VP]),
     "spr_synth_queries": (C.c_int, [_VP, _I64, _I64, _VP, _I32, _I32, _I32, C.c_uint64, _I32, _I32, _I32, _VP]),
 }

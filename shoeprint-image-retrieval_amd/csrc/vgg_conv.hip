@@ -1,0 +1,393 @@
+// VGG16 feature extractor: torchvision vgg16().features[:block] (network.py:125-134, 185-186, 235).
+//
+// Every 3x3 / stride 1 / pad 1 convolution is an implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32, bit-for-bit a k-ordered fmaf chain), with bias, ReLU and the
+// 2x2 max-pool that follows it fused into the epilogue.  Activations between layers are NHWC in HBM
+// (the GEMM's K index = input channel is then contiguous); the last layer writes NCHW float32, the
+// layout Model.get_feature_maps returns (network.py:241-244) and the NCC prep kernels read.
+//
+// conv_mfma_kernel, one workgroup = 16x16 output pixels x 64 output channels, 4 waves, wave w owns
+// output rows 4w..4w+3 (4 row segments of 16 pixels = 4 A blocks) x 4 blocks of 16 channels:
+//   for every chunk of 16 input channels:   stage the 18x18x16 input patch and the 9x64x16 filter slab
+//                                           in LDS (16-byte loads, zero fill outside the image)
+//     for every tap (dy,dx):                4 A fragments (ds_read_b128: 4 input channels per lane) and
+//                                           4 B fragments feed 4x4x4 MFMAs; the k index of MFMA j is
+//                                           {4q+j : q = 0..3} for both operands (any partition of the 16
+//                                           channels works as long as A and B agree).
+// Arithmetic per image at 512x256 up to conv3_3: 48.77 GFLOP (SURVEY §8 a-E2); bound: fp32 MFMA 157 TFLOP/s.
+//
+// conv_first_kernel: conv1_1 has 3 input planes (K = 27, 0.9 % of the flops): plain FMA kernel that
+// also applies ToTensor / repeat(3) / Normalize (network.py:60-71) — x'_c = (u8/255 - mean_c) * inv_std_c,
+// zero padding AFTER normalisation.
+#include <new>
+#include <vector>
+
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+constexpr int kTile = 16;       // output tile edge (pixels)
+constexpr int kPatch = kTile + 2;
+constexpr int kCk = 16;         // input channels per chunk
+constexpr int kCS = 20;         // LDS stride (floats) of one patch pixel / one filter row: 16 + 4 pad
+constexpr int kTN = 64;         // output channels per workgroup
+
+struct Stage {
+  int cin, cout;
+  int relu, pool;
+  size_t w_off, b_off;  // float offsets into the packed parameter buffer
+};
+
+// ---------------------------------------------------------------- parameter packing
+// first conv: [tap*3 + c][64]  |  MFMA convs: [cout/64][cin/16][tap][n:64][c:16]
+__global__ void __launch_bounds__(kThreads)
+pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ packed,
+                    size_t w_off, size_t b_off, int cin, int cout, int first) {
+  const size_t total = static_cast<size_t>(cout) * cin * 9;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    // i indexes the torch layout [n][c][ky][kx]
+    const int tap = static_cast<int>(i % 9);
+    const int c = static_cast<int>((i / 9) % cin);
+    const int n = static_cast<int>(i / (static_cast<size_t>(9) * cin));
+    size_t dst;
+    if (first) {
+      dst = static_cast<size_t>(tap * 3 + c) * cout + n;
+    } else {
+      const int cb = n / kTN, nn = n % kTN, cc = c / kCk, ci = c % kCk;
+      dst = ((((static_cast<size_t>(cb) * (cin / kCk) + cc) * 9 + tap) * kTN + nn) * kCk) + ci;
+    }
+    packed[w_off + dst] = w[i];
+  }
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
+}
+
+// ---------------------------------------------------------------- conv1_1 (+ pre-processing)
+// grid = (tiles, n images); out NHWC [n][H][W][64] or NCHW when it is the last stage.
+__global__ void __launch_bounds__(kThreads)
+conv_first_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2,
+                  float s0, float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias,
+                  int relu, int nchw, float* __restrict__ out) {
+  __shared__ float patch[kPatch * kPatch * 3];
+  __shared__ float wl[27 * 64 + 64];
+  const int tiles_x = ceil_div(W, kTile);
+  const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
+  const int y0 = ty * kTile, x0 = tx * kTile;
+  const size_t img = blockIdx.y;
+  const int tid = static_cast<int>(threadIdx.x);
+  const float mean[3] = {m0, m1, m2}, istd[3] = {s0, s1, s2};
+  for (int i = tid; i < kPatch * kPatch; i += kThreads) {
+    const int py = i / kPatch, px = i % kPatch;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool in = y >= 0 && y < H && x >= 0 && x < W;
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.0f;  // zero padding of the NORMALISED tensor (network.py:69 then conv padding)
+      if (in) {
+        const size_t pix = (img * H + y) * static_cast<size_t>(W) + x;
+        const float u = static_cast<float>(in_channels == 1 ? images[pix] : images[pix * 3 + c]);
+        v = (u / 255.0f - mean[c]) * istd[c];  // ToTensor then Normalize, in this order (network.py:64-69)
+      }
+      patch[i * 3 + c] = v;
+    }
+  }
+  for (int i = tid; i < 27 * 64; i += kThreads) wl[i] = wts[i];
+  for (int i = tid; i < 64; i += kThreads) wl[27 * 64 + i] = bias[i];
+  __syncthreads();
+  const int py = tid / kTile, px = tid % kTile;
+  const int y = y0 + py, x = x0 + px;
+  float acc[64];
+#pragma unroll
+  for (int n = 0; n < 64; ++n) acc[n] = wl[27 * 64 + n];
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = patch[((py + dy) * kPatch + (px + dx)) * 3 + c];
+      const float* wr = wl + (tap * 3 + c) * 64;
+#pragma unroll
+      for (int n = 0; n < 64; ++n) acc[n] = fmaf(v, wr[n], acc[n]);
+    }
+  }
+  if (y < H && x < W) {
+#pragma unroll
+    for (int n = 0; n < 64; ++n) {
+      const float v = relu ? fmaxf(acc[n], 0.0f) : acc[n];
+      if (nchw) out[((img * 64 + n) * H + y) * static_cast<size_t>(W) + x] = v;
+      else out[((img * H + y) * static_cast<size_t>(W) + x) * 64 + n] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 3x3 conv on fp32 MFMA
+// grid = (tiles, cout/64, n images)
+__global__ void __launch_bounds__(kThreads, 2)
+conv_mfma_kernel(const float* __restrict__ in, int H, int W, int cin, int cout, const float* __restrict__ wts,
+                 const float* __restrict__ bias, int relu, int pool, int nchw, float* __restrict__ out) {
+  unsigned char* lds = dyn_lds();
+  float* patch = reinterpret_cast<float*>(lds);                 // [18*18][kCS]
+  float* wl = patch + kPatch * kPatch * kCS;                    // [9*64][kCS]
+  const int tiles_x = ceil_div(W, kTile);
+  const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
+  const int y0 = ty * kTile, x0 = tx * kTile;
+  const int cb = static_cast<int>(blockIdx.y);
+  const size_t img = blockIdx.z;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int p = lane & 15, q = lane >> 4;  // MFMA lane coordinates: row/col index, k index
+  const int nchunks = cin / kCk;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* in_img = in + img * static_cast<size_t>(H) * W * cin;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // the previous chunk's fragments are consumed
+    // ---- stage the input patch: 324 pixels x 16 channels, one 16-byte piece per (pixel, quarter)
+    for (int i = tid; i < kPatch * kPatch * 4; i += kThreads) {
+      const int pp = i >> 2, qq = i & 3;
+      const int y = y0 - 1 + pp / kPatch, x = x0 - 1 + pp % kPatch;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y >= 0 && y < H && x >= 0 && x < W)
+        v = *reinterpret_cast<const float4*>(in_img + (static_cast<size_t>(y) * W + x) * cin + cc * kCk + qq * 4);
+      *reinterpret_cast<float4*>(patch + pp * kCS + qq * 4) = v;
+    }
+    // ---- stage the filter slab [tap][n][16] of this (cout block, chunk): contiguous in the packed buffer
+    const float* wsrc = wts + (static_cast<size_t>(cb) * nchunks + cc) * (9 * kTN * kCk);
+    for (int i = tid; i < 9 * kTN * 4; i += kThreads) {
+      const int row = i >> 2, qq = i & 3;
+      *reinterpret_cast<float4*>(wl + row * kCS + qq * 4) = *reinterpret_cast<const float4*>(wsrc + row * kCk + qq * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      float4 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a[i] = *reinterpret_cast<const float4*>(patch + ((wave * 4 + i + dy) * kPatch + (p + dx)) * kCS + q * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        b[j] = *reinterpret_cast<const float4*>(wl + ((tap * kTN) + j * 16 + p) * kCS + q * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = mfma_f32_16x16x4(a[i].x, b[j].x, acc[i][j]);
+          acc[i][j] = mfma_f32_16x16x4(a[i].y, b[j].y, acc[i][j]);
+          acc[i][j] = mfma_f32_16x16x4(a[i].z, b[j].z, acc[i][j]);
+          acc[i][j] = mfma_f32_16x16x4(a[i].w, b[j].w, acc[i][j]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane (q, p) owns output pixels x0 + 4q + jj (jj = 0..3) of rows y0 + 4*wave + i,
+  //      channel cb*64 + 16j + p  (MFMA C/D map: row = 4*(lane>>4) + reg, col = lane & 15)
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = cb * kTN + j * 16 + p;
+    const float bv = bias[ch];
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float t = acc[i][j][jj] + bv;
+        v[i][jj] = relu ? fmaxf(t, 0.0f) : t;
+      }
+    if (pool) {
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+          const float m = fmaxf(fmaxf(v[2 * i2][2 * j2], v[2 * i2][2 * j2 + 1]),
+                                fmaxf(v[2 * i2 + 1][2 * j2], v[2 * i2 + 1][2 * j2 + 1]));
+          const int y = (y0 + 4 * wave) / 2 + i2, x = (x0 + 4 * q) / 2 + j2;
+          if (y < Ho && x < Wo) {
+            if (nchw) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = m;
+            else out[((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + ch] = m;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int y = y0 + 4 * wave + i, x = x0 + 4 * q + jj;
+          if (y < Ho && x < Wo) {
+            if (nchw) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = v[i][jj];
+            else out[((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + ch] = v[i][jj];
+          }
+        }
+    }
+  }
+}
+
+constexpr size_t kConvLds = sizeof(float) * (kPatch * kPatch * kCS + 9 * kTN * kCS);
+
+}  // namespace
+}  // namespace spr
+
+struct spr_vgg16_plan {
+  int block;
+  std::vector<spr::Stage> stages;
+  size_t packed_floats;
+};
+
+using namespace spr;
+
+extern "C" int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out) {
+  if (!plan_out) { set_error("spr_vgg16_plan_create: null pointer"); return SPR_ERR_ARG; }
+  *plan_out = nullptr;
+  // torchvision vgg16 cfg "D": 64,64,M,128,128,M,256,256,256,M,512,512,512,M,512,512,512,M
+  static const int cfg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -1, 512, 512, 512, -1, 512, 512, 512, -1};
+  struct Op { char kind; int cin, cout; };
+  std::vector<Op> ops;
+  int c = 3;
+  for (int v : cfg) {
+    if (v < 0) ops.push_back({'P', c, c});
+    else { ops.push_back({'C', c, v}); ops.push_back({'R', v, v}); c = v; }
+  }
+  if (block < 1 || block > static_cast<int>(ops.size())) {
+    set_error("spr_vgg16_plan_create: block %d outside [1, %zu] (len(vgg16.features) = 31)", block, ops.size());
+    return SPR_ERR_ARG;
+  }
+  spr_vgg16_plan* plan = new (std::nothrow) spr_vgg16_plan();
+  if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
+  plan->block = block;
+  size_t off = 0;
+  for (int i = 0; i < block; ++i) {
+    if (ops[i].kind != 'C') continue;  // R and P are fused into the preceding convolution
+    Stage s{};
+    s.cin = ops[i].cin; s.cout = ops[i].cout;
+    s.relu = (i + 1 < block && ops[i + 1].kind == 'R') ? 1 : 0;
+    s.pool = (s.relu && i + 2 < block && ops[i + 2].kind == 'P') ? 1 : 0;
+    s.w_off = off; off += static_cast<size_t>(s.cout) * s.cin * 9;
+    s.b_off = off; off += static_cast<size_t>(s.cout);
+    off = (off + 3) / 4 * 4;  // keep every slab 16-byte aligned
+    plan->stages.push_back(s);
+  }
+  plan->packed_floats = off;
+  *plan_out = plan;
+  return SPR_OK;
+}
+
+extern "C" void spr_vgg16_plan_destroy(spr_vgg16_plan* plan) { delete plan; }
+
+extern "C" int spr_vgg16_num_convs(const spr_vgg16_plan* plan) {
+  return plan ? static_cast<int>(plan->stages.size()) : SPR_ERR_ARG;
+}
+
+extern "C" int spr_vgg16_conv_shape(const spr_vgg16_plan* plan, int32_t i, int32_t* cin, int32_t* cout) {
+  if (!plan || !cin || !cout || i < 0 || i >= static_cast<int>(plan->stages.size())) {
+    set_error("spr_vgg16_conv_shape: bad argument");
+    return SPR_ERR_ARG;
+  }
+  *cin = plan->stages[i].cin;
+  *cout = plan->stages[i].cout;
+  return SPR_OK;
+}
+
+extern "C" int spr_vgg16_output_shape(const spr_vgg16_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels,
+                                      int32_t* out_h, int32_t* out_w) {
+  if (!plan || !channels || !out_h || !out_w || in_h < 1 || in_w < 1) {
+    set_error("spr_vgg16_output_shape: bad argument");
+    return SPR_ERR_ARG;
+  }
+  int h = in_h, w = in_w, c = 3;
+  for (const Stage& s : plan->stages) {
+    c = s.cout;
+    if (s.pool) { h /= 2; w /= 2; }
+  }
+  if (h < 1 || w < 1) { set_error("image %dx%d vanishes under the pools of features[:%d]", in_h, in_w, plan->block); return SPR_ERR_SHAPE; }
+  *channels = c; *out_h = h; *out_w = w;
+  return SPR_OK;
+}
+
+extern "C" size_t spr_vgg16_packed_bytes(const spr_vgg16_plan* plan) {
+  return plan ? plan->packed_floats * sizeof(float) : 0;
+}
+
+extern "C" int spr_vgg16_pack_weights(spr_vgg16_plan* plan, const float* const* weights, const float* const* biases,
+                                      void* packed, spr_stream_t stream) {
+  if (!plan || !weights || !biases || !packed) { set_error("spr_vgg16_pack_weights: null pointer"); return SPR_ERR_ARG; }
+  for (size_t i = 0; i < plan->stages.size(); ++i) {
+    const Stage& s = plan->stages[i];
+    if (!weights[i] || !biases[i]) { set_error("spr_vgg16_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(256), dim3(kThreads), 0, static_cast<hipStream_t>(stream), weights[i],
+                       biases[i], static_cast<float*>(packed), s.w_off, s.b_off, s.cin, s.cout, i == 0 ? 1 : 0);
+    const int rc = check_launch("pack_weights_kernel");
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
+}
+
+static size_t stage_out_floats(const Stage& s, int64_t n, int h, int w) {
+  const int ho = s.pool ? h / 2 : h, wo = s.pool ? w / 2 : w;
+  return static_cast<size_t>(n) * ho * wo * s.cout;
+}
+
+extern "C" size_t spr_vgg16_workspace_bytes(const spr_vgg16_plan* plan, int64_t n, int32_t in_h, int32_t in_w) {
+  if (!plan || n < 0) return 0;
+  // two ping-pong activation buffers, each as large as the largest intermediate tensor
+  size_t biggest = 0;
+  int h = in_h, w = in_w;
+  for (size_t i = 0; i + 1 < plan->stages.size(); ++i) {
+    const Stage& s = plan->stages[i];
+    const size_t f = stage_out_floats(s, n, h, w);
+    if (f > biggest) biggest = f;
+    if (s.pool) { h /= 2; w /= 2; }
+  }
+  return 2 * align_up(biggest * sizeof(float), 256);
+}
+
+extern "C" int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                                 int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                                 void* workspace, float* out, spr_stream_t stream) {
+  if (!plan) { set_error("spr_vgg16_forward: null plan"); return SPR_ERR_ARG; }
+  if (n < 0 || n > 65535 || in_h < 1 || in_w < 1 || (in_channels != 1 && in_channels != 3)) {
+    set_error("spr_vgg16_forward: bad sizes (n in [0, 65535], in_channels 1 or 3)");
+    return SPR_ERR_ARG;
+  }
+  if (n == 0) return SPR_OK;
+  if (!images || !mean3 || !inv_std3 || !packed || !out || (plan->stages.size() > 1 && !workspace)) {
+    set_error("spr_vgg16_forward: null pointer");
+    return SPR_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* pk = static_cast<const float*>(packed);
+  const size_t half = spr_vgg16_workspace_bytes(plan, n, in_h, in_w) / 2;
+  float* buf[2] = {static_cast<float*>(workspace),
+                   reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + half)};
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kConvLds));
+  int h = in_h, w = in_w;
+  const float* cur = nullptr;
+  for (size_t i = 0; i < plan->stages.size(); ++i) {
+    const Stage& st = plan->stages[i];
+    const bool last = i + 1 == plan->stages.size();
+    float* dst = last ? out : buf[i & 1];
+    const unsigned tiles = static_cast<unsigned>(ceil_div(h, kTile) * ceil_div(w, kTile));
+    if (i == 0) {
+      hipLaunchKernelGGL(conv_first_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, h, w,
+                         in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2],
+                         pk + st.w_off, pk + st.b_off, st.relu, last ? 1 : 0, dst);
+      const int rc = check_launch("conv_first_kernel");
+      if (rc != SPR_OK) return rc;
+    } else {
+      hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, static_cast<unsigned>(st.cout / kTN), static_cast<unsigned>(n)),
+                         dim3(kThreads), kConvLds, s, cur, h, w, st.cin, st.cout, pk + st.w_off, pk + st.b_off, st.relu,
+                         st.pool, last ? 1 : 0, dst);
+      const int rc = check_launch("conv_mfma_kernel");
+      if (rc != SPR_OK) return rc;
+    }
+    if (st.pool) { h /= 2; w /= 2; }
+    cur = dst;
+  }
+  return SPR_OK;
+}

@@ -1,0 +1,180 @@
+"""Feature extractor on MI355X — host mirror of the reference's ``network.py``.
+
+Drop-in for ``src/shoeprint_image_retrieval/network.py``:
+
+* ``Model(config, block)``                                        (network.py:93-97)
+* ``Model.get_feature_maps(img) -> float32 [C, h, w]``            (network.py:210-244)
+* ``Model.get_multiple_feature_maps(images, *, progress=True)``   (network.py:246-269)
+
+``block`` is the slice end into ``vgg16().features`` (network.py:185).  The forward pass is the HIP
+library's ``spr_vgg16_forward`` (implicit-GEMM 3x3 convolutions on the fp32 matrix cores with bias /
+ReLU / max-pool fused, pre-processing fused into the first layer) and — unlike the reference's one
+image per launch (network.py:228) — runs whole batches; ``extract_device`` keeps the features in HBM
+for the scorer.  Unknown ``model.type`` raises ``LookupError("Model string not found")`` as the
+reference does (network.py:180-182); the reference's other backbones (VGG19, EfficientNet*, DenseNet)
+are not built and raise ``NotImplementedError``.
+
+Weights: torchvision downloads ``IMAGENET1K_FEATURES`` by name (network.py:126), impossible offline.
+``config["mi355x"]["weights"]`` may name a local state dict (``features.N.weight/bias``, loaded with
+``torch.load(weights_only=True)``); otherwise seeded He-normal weights from ``synth.vgg16_parameters``
+are used (and a warning is printed once).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from typing import Any
+
+import numpy as np
+
+from . import _lib, clahe as _clahe_mod, synth
+
+VGG16_MEAN = (0.48235, 0.45882, 0.40784)                     # network.py:128
+VGG16_STD = (0.00392156862745098,) * 3                       # network.py:129
+_CONV_INDEX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)   # positions of the convolutions in vgg16().features
+_REFERENCE_MODELS = {"VGG19", "VGG19_BN", "EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
+                     "EfficientNet_B5", "EfficientNet_B7", "EfficientNetV2_S", "EfficientNetV2_M", "EfficientNetV2_L",
+                     "DenseNet_201"}
+_warned = False
+
+
+class Model:
+    """Operate on the truncated VGG16 and its pre-processing (reference network.py:90-269)."""
+
+    def __init__(self, config: dict, block: int, *, device=None, library: _lib.Library | None = None,
+                 parameters: list[tuple[np.ndarray, np.ndarray]] | None = None, batch_size: int = 16):
+        self.config = config
+        model_cfg = config["model"]
+        self.clahe_clip_limit = float(model_cfg.get("clahe_clip_limit", 2.0))
+        self.clahe_tile_grid_size = tuple(model_cfg.get("clahe_tile_grid_size", (8, 8)))
+        model_str = model_cfg["type"]
+        if model_str != "VGG16":
+            if model_str in _REFERENCE_MODELS:
+                raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); use VGG16")
+            raise LookupError("Model string not found")  # network.py:180-182
+        self.mean, self.std = VGG16_MEAN, VGG16_STD
+        self.block = int(block)
+        self.batch_size = int(batch_size)
+        self.lib = library or _lib.load_library()
+        if device is None:
+            from .device import TorchDevice
+
+            device = TorchDevice()
+        self.dev = device
+        handle = C.c_void_p()
+        self.lib.check(self.lib.spr_vgg16_plan_create(self.block, C.byref(handle)))
+        self.handle = handle
+        self.n_convs = self.lib.spr_vgg16_num_convs(handle)
+        if parameters is None:
+            parameters = self._load_parameters(config)
+        self._set_parameters(parameters)
+
+    # ------------------------------------------------------------------ parameters
+    def conv_shapes(self) -> list[tuple[int, int]]:
+        out = []
+        for i in range(self.n_convs):
+            cin, cout = C.c_int32(), C.c_int32()
+            self.lib.check(self.lib.spr_vgg16_conv_shape(self.handle, i, C.byref(cin), C.byref(cout)))
+            out.append((cin.value, cout.value))
+        return out
+
+    def _load_parameters(self, config):
+        global _warned
+        path = config.get("mi355x", {}).get("weights", "")
+        if path:
+            import torch
+
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            params = []
+            for i in range(self.n_convs):
+                k = _CONV_INDEX[i]
+                params.append((state[f"features.{k}.weight"].float().numpy(), state[f"features.{k}.bias"].float().numpy()))
+            return params
+        if not _warned:
+            print("shoeprint_image_retrieval_amd: no [mi355x].weights given — using seeded synthetic VGG16 weights "
+                  "(pretrained IMAGENET1K_FEATURES cannot be downloaded offline)", file=sys.stderr)
+            _warned = True
+        return synth.vgg16_parameters(1234, self.conv_shapes())
+
+    def _set_parameters(self, parameters):
+        shapes = self.conv_shapes()
+        if len(parameters) < len(shapes):
+            raise ValueError(f"{len(shapes)} convolutions need parameters, got {len(parameters)}")
+        dev = self.dev
+        self._w_dev, self._b_dev = [], []
+        for (cin, cout), (w, b) in zip(shapes, parameters):
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            if w.shape != (cout, cin, 3, 3) or b.shape != (cout,):
+                raise ValueError(f"parameter shape {w.shape}/{b.shape} does not match conv {cin}->{cout}")
+            self._w_dev.append(dev.to_device(w))
+            self._b_dev.append(dev.to_device(b))
+        n = len(shapes)
+        wp = (C.c_void_p * n)(*[dev.ptr(t) for t in self._w_dev])
+        bp = (C.c_void_p * n)(*[dev.ptr(t) for t in self._b_dev])
+        self.packed = dev.empty_bytes(max(16, self.lib.spr_vgg16_packed_bytes(self.handle)))
+        self.lib.check(self.lib.spr_vgg16_pack_weights(self.handle, wp, bp, dev.ptr(self.packed), dev.stream()))
+        dev.synchronize()
+
+    # ------------------------------------------------------------------ shapes
+    def output_shape(self, in_h: int, in_w: int) -> tuple[int, int, int]:
+        c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.check(self.lib.spr_vgg16_output_shape(self.handle, in_h, in_w, C.byref(c), C.byref(h), C.byref(w)))
+        return c.value, h.value, w.value
+
+    # ------------------------------------------------------------------ forward
+    def extract_device(self, images_dev, in_channels: int = 1):
+        """uint8 device batch [N,H,W] (or [N,H,W,3]) -> float32 device features [N,C,h,w] (stays in HBM)."""
+        dev = self.dev
+        shape = dev.shape(images_dev)
+        n, h, w = shape[0], shape[1], shape[2]
+        c, oh, ow = self.output_shape(h, w)
+        out = dev.empty((n, c, oh, ow), np.float32)
+        ws = dev.empty_bytes(max(16, self.lib.spr_vgg16_workspace_bytes(self.handle, n, h, w)))
+        mean = (C.c_float * 3)(*self.mean)
+        inv_std = (C.c_float * 3)(*[np.float32(1.0) / np.float32(s) for s in self.std])
+        self.lib.check(self.lib.spr_vgg16_forward(self.handle, dev.ptr(images_dev), n, h, w, in_channels, mean, inv_std,
+                                                  dev.ptr(self.packed), dev.ptr(ws), dev.ptr(out), dev.stream()))
+        return out
+
+    def _clahe(self, img: np.ndarray) -> np.ndarray:
+        """CLAHE before the network (network.py:197-208); grey images only (the LAB route for RGB is not built)."""
+        if img.ndim == 3:
+            raise NotImplementedError("CLAHE of RGB images (RGB->LAB->CLAHE(L)->RGB, network.py:199-204) is not built")
+        return _clahe_mod.clahe(img, self.clahe_clip_limit, self.clahe_tile_grid_size)
+
+    def get_feature_maps(self, img: np.ndarray) -> np.ndarray:
+        """One image (uint8 [H,W]) -> float32 [C,h,w], a fresh C-contiguous array (network.py:210-244)."""
+        return self.get_multiple_feature_maps([img], progress=False)[0]
+
+    def get_multiple_feature_maps(self, images: list[np.ndarray], *, progress: bool = True) -> list[np.ndarray]:
+        """List of images -> list of feature stacks (network.py:246-269).  Images of equal size are
+        batched through one launch sequence; sizes may differ between images."""
+        results: list[Any] = [None] * len(images)
+        groups: dict[tuple, list[int]] = {}
+        for i, im in enumerate(images):
+            groups.setdefault(tuple(im.shape), []).append(i)
+        done = 0
+        for shape, idx in groups.items():
+            for start in range(0, len(idx), self.batch_size):
+                part = idx[start:start + self.batch_size]
+                batch = np.stack([self._clahe(np.ascontiguousarray(images[i], dtype=np.uint8)) for i in part])
+                feats = self.dev.to_host(self.extract_device(self.dev.to_device(batch), in_channels=1))
+                for k, i in enumerate(part):
+                    results[i] = np.ascontiguousarray(feats[k])
+                done += len(part)
+                if progress:
+                    print(f"\rfeatures {done}/{len(images)}", end="" if done < len(images) else "\n", file=sys.stderr)
+        return results
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.spr_vgg16_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -115,3 +115,16 @@ def shoeprint_image(seed: int, item: int, h: int = 512, w: int = 256) -> np.ndar
     f = f / (np.abs(f).max() + 1e-9)
     img = 127.5 + 127.5 * np.tanh(6.0 * f)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def vgg16_parameters(seed: int, conv_shapes) -> list[tuple[np.ndarray, np.ndarray]]:
+    """Seeded He-normal weights [cout,cin,3,3] and small biases [cout] for every convolution
+    (pretrained weights cannot be fetched offline)."""
+    params = []
+    for i, (cin, cout) in enumerate(conv_shapes):
+        n = cout * cin * 9
+        w = irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 2 * i), np.arange(n, dtype=np.int64)).astype(np.float32)
+        w = (w * np.float32(np.sqrt(2.0 / (cin * 9)) / 37837.0)).reshape(cout, cin, 3, 3)
+        b = irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 2 * i + 1), np.arange(cout, dtype=np.int64)).astype(np.float32)
+        params.append((w, b * np.float32(0.05 / 37837.0)))
+    return params

@@ -1,0 +1,75 @@
+"""Extractor parity checks shared by the emulated (not gpu) and MI355X (gpu) tests.
+Oracle = torch-CPU float32 ops with the same seeded weights (oracle/vgg_oracle.py; unpinned by the
+reference, see its header).  Tolerance: 2e-5 of the largest activation (float32 summation order)."""
+
+import numpy as np
+
+from oracle import ncc_oracle, vgg_oracle
+from shoeprint_image_retrieval_amd import network, similarity, synth
+
+CFG = {"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]},
+       "comparison": {"n_processes": 2, "rotations": None, "scales": None}}
+
+
+def make_model(block, device, lib, **kw):
+    return network.Model(CFG, block, device=device, library=lib, **kw)
+
+
+def check_block(block, hw, device, lib, n_images=2):
+    m = make_model(block, device, lib)
+    params = synth.vgg16_parameters(1234, m.conv_shapes())
+    assert m.conv_shapes() == vgg_oracle.conv_shapes(block)
+    imgs = np.stack([synth.shoeprint_image(5, i, *hw) for i in range(n_images)])
+    got = device.to_host(m.extract_device(device.to_device(imgs)))
+    assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    for i in range(n_images):
+        ref = vgg_oracle.get_feature_maps(imgs[i], block, params)
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
+    m.close()
+
+
+def check_reference_surface(device, lib):
+    """Model(config, block), get_feature_maps, get_multiple_feature_maps keep the reference's behaviour."""
+    m = make_model(5, device, lib, batch_size=2)
+    params = synth.vgg16_parameters(1234, m.conv_shapes())
+    imgs = [synth.shoeprint_image(9, i, 40, 32) for i in range(3)] + [synth.shoeprint_image(9, 7, 24, 48)]
+    maps = m.get_multiple_feature_maps(imgs, progress=False)
+    assert isinstance(maps, list) and len(maps) == 4
+    for im, fm in zip(imgs, maps):
+        assert fm.dtype == np.float32 and fm.flags["C_CONTIGUOUS"] and fm.ndim == 3
+        ref = vgg_oracle.get_feature_maps(m._clahe(im), 5, params)
+        np.testing.assert_allclose(fm, ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
+    single = m.get_feature_maps(imgs[1])
+    np.testing.assert_array_equal(single, maps[1])
+    for bad, exc in (("NoSuchNet", LookupError), ("EfficientNetV2_M", NotImplementedError)):
+        cfg = {"model": dict(CFG["model"], type=bad)}
+        try:
+            network.Model(cfg, 5, device=device, library=lib)
+        except exc as e:
+            if exc is LookupError:
+                assert str(e) == "Model string not found"  # network.py:181
+        else:
+            raise AssertionError(bad)
+
+
+def check_end_to_end(device, lib, scorer, block=10, hw=(64, 48), n_gallery=6, n_queries=3):
+    """SURVEY §8d config 1 in miniature: images -> Model -> compare_maps, against the oracle chain."""
+    m = make_model(block, device, lib)
+    params = synth.vgg16_parameters(1234, m.conv_shapes())
+    gallery = [synth.shoeprint_image(21, g, *hw) for g in range(n_gallery)]
+    rng = np.random.default_rng(3)
+    queries = []
+    for q in range(n_queries):  # degraded copies of gallery[q]: noise + a small shift
+        im = np.roll(gallery[q].astype(np.int32), (2, -3), axis=(0, 1)) + rng.normal(0, 25, hw)
+        queries.append(np.clip(im, 0, 255).astype(np.uint8))
+    matches = list(range(n_queries))
+    gf = m.get_multiple_feature_maps(gallery, progress=False)
+    qf = m.get_multiple_feature_maps(queries, progress=False)
+    ranks = similarity.compare_maps(qf, gf, matches, CFG, scorer=scorer)
+    ref_gf = [vgg_oracle.get_feature_maps(m._clahe(im), block, params) for im in gallery]
+    ref_qf = [vgg_oracle.get_feature_maps(m._clahe(im), block, params) for im in queries]
+    ref_ranks, ref_mat = ncc_oracle.compare_maps(ref_qf, ref_gf, matches, CFG, return_matrix=True)
+    mat = scorer.score_matrix(qf, gf)
+    np.testing.assert_allclose(mat, ref_mat, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(ranks, ref_ranks)

@@ -146,3 +146,38 @@ def test_oracle_sample_at_full_size(fft_scorer, lib):
     got = dev.to_host(sc.scores_device(q, g))
     ref = oracle.similarity_matrix(list(dev.to_host(q)), list(dev.to_host(g)), precise=True)
     np.testing.assert_allclose(got, ref, atol=1e-5, rtol=0)
+
+
+# ------------------------------------------------------------------------------ extractor (VGG16 on MFMA)
+@pytest.fixture(scope="module")
+def torch_dev():
+    from shoeprint_image_retrieval_amd.device import TorchDevice
+
+    return TorchDevice()
+
+
+@pytest.mark.parametrize("block,hw", [(2, (20, 24)), (5, (36, 40)), (10, (40, 36)), (16, (64, 48)), (17, (64, 48)),
+                                      (23, (64, 64)), (30, (64, 64))])
+def test_vgg16_truncations(block, hw, torch_dev, lib):
+    import extractor_cases as ec
+
+    ec.check_block(block, hw, torch_dev, lib)
+
+
+def test_vgg16_conv3_3_full_size_image(torch_dev, lib):
+    """512x256 print through features[:16] (the headline extractor shape) vs torch-CPU."""
+    import extractor_cases as ec
+
+    ec.check_block(16, (512, 256), torch_dev, lib, n_images=1)
+
+
+def test_extractor_reference_surface(torch_dev, lib):
+    import extractor_cases as ec
+
+    ec.check_reference_surface(torch_dev, lib)
+
+
+def test_end_to_end_pipeline(torch_dev, lib, fft_scorer):
+    import extractor_cases as ec
+
+    ec.check_end_to_end(torch_dev, lib, fft_scorer, block=16, hw=(128, 96), n_gallery=10, n_queries=4)
