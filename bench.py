@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--method", default="auto", choices=["auto", "fft", "direct"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-sample", action="store_true")
+    ap.add_argument("--no-extractor", action="store_true")
     ap.add_argument("--cpu-sample-gallery", type=int, default=0, help="gallery items in the CPU sample (0 = auto)")
     args = ap.parse_args()
 
@@ -193,6 +194,27 @@ def main():
         "rank1": round(parse_results.rank1(ranks), 4), "mAP": round(parse_results.mean_average_precision(ranks), 4),
         "roofline": roofline,
     }
+
+    if rank == 0 and not args.no_extractor:
+        # extractor reported separately: VGG16 features[:16] on 512x256 prints, images/s
+        from shoeprint_image_retrieval_amd import network
+        model = network.Model({"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 16)
+        imgs = torch.randint(0, 256, (32, 2 * H * 2, 2 * W * 2), dtype=torch.uint8, device=gallery.device)
+        model.extract_device(imgs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            model.extract_device(imgs)
+        e1.record()
+        torch.cuda.synchronize()
+        ems = e0.elapsed_time(e1) / 3
+        out["extractor"] = {"metric": "VGG16 features[:16] images/s (512x256 uint8 -> [256,128,64] f32)",
+                            "value": round(32 / ems * 1e3, 1), "batch": 32, "ms_per_batch": round(ems, 2),
+                            "achieved_tflops": round(48.77 * 32 / ems, 2), "peak_tflops": PEAK_FP32_TFLOPS,
+                            "frac": round(48.77 * 32 / ems / PEAK_FP32_TFLOPS, 4), "bound": "mfma", "dtype": "f32",
+                            "weights": "seeded synthetic"}
+        del model, imgs
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives a one-GPU job a 16-core share of the host (nproc still reports every core)
