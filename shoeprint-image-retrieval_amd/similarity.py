@@ -186,13 +186,16 @@ class NccScorer:
         return out
 
     # ------------------------------------------------------------------ list-of-arrays level
-    def score_matrix(self, shoemark_maps, shoeprint_maps, accumulate_into=None) -> np.ndarray:
+    def score_matrix(self, shoemark_maps, shoeprint_maps, accumulate_into=None, rotations=None,
+                     scales=None) -> np.ndarray:
         """Host float32 [Q,G] matrix for the reference's list-of-arrays inputs, including ragged
         sets (items of different spatial size): items are grouped by shape and every
-        (query shape, gallery shape) class is one plan."""
+        (query shape, gallery shape) class is one plan.  With ``rotations`` / ``scales`` every query
+        batch is expanded on the device into the reference's variant list (variants.py) and the
+        matrix keeps the running maximum over variants (similarity.py:357-367)."""
         q_items, q_dev = _as_item_list(shoemark_maps)
         g_items, g_dev = _as_item_list(shoeprint_maps)
-        if q_items is None and g_items is None:
+        if q_items is None and g_items is None and rotations is None and scales is None:
             scores = self.scores_device(q_dev, g_dev)
             return self.dev.to_host(scores)
         if q_items is None:
@@ -205,20 +208,30 @@ class NccScorer:
             return out
         q_groups = _group_by_shape(q_items)
         g_groups = _group_by_shape(g_items)
+        from .variants import VariantBuilder
+
+        builder = VariantBuilder(self.lib, self.dev)
         for qshape, q_idx in q_groups.items():
             q_batch = self.dev.to_device(_stack32(q_items, q_idx))
+            variants = builder.variants(q_batch, rotations, scales)
+            by_shape: dict[tuple, list] = {}  # variants of one shape share a plan and the prepared gallery
+            for v in variants:
+                by_shape.setdefault(tuple(self.dev.shape(v)[2:]), []).append(v)
             for gshape, g_idx in g_groups.items():
                 if qshape[0] != gshape[0]:
                     raise ValueError(f"channel mismatch: query {qshape}, gallery {gshape}")
-                plan = self.plan(qshape[0], qshape[1:], gshape[1:])
-                pq = self.prepare_queries(plan, q_batch)
-                chunk = self.gallery_chunk_items(plan, len(g_idx))
+                plans = {vs: self.plan(qshape[0], vs, gshape[1:]) for vs in by_shape}
+                chunk = min(self.gallery_chunk_items(p, len(g_idx)) for p in plans.values())
                 for start in range(0, len(g_idx), chunk):
                     idx = g_idx[start:start + chunk]
                     g_batch = self.dev.to_device(_stack32(g_items, idx))
-                    pg = self.prepare_gallery(plan, g_batch)
                     sub = self.dev.zeros((len(q_idx), len(idx)), np.float32)
-                    self.score_prepared(plan, pq, len(q_idx), pg, len(idx), sub, len(idx), 0)
+                    for vs, vlist in by_shape.items():
+                        plan = plans[vs]
+                        pg = self.prepare_gallery(plan, g_batch)
+                        for v in vlist:
+                            pq = self.prepare_queries(plan, v)
+                            self.score_prepared(plan, pq, len(q_idx), pg, len(idx), sub, len(idx), 0, accumulate_max=True)
                     sub_h = self.dev.to_host(sub)
                     block = out[np.ix_(q_idx, idx)]
                     out[np.ix_(q_idx, idx)] = np.maximum(block, sub_h)
@@ -276,17 +289,14 @@ def compare_maps(
 
     ``matching_pairs[i]`` is the index into ``shoeprint_maps`` of query i's true match;
     ``config["comparison"]`` supplies ``n_processes`` (ignored: the GPU grid replaces the
-    process pool), ``rotations`` and ``scales``.
+    process pool), ``rotations`` and ``scales`` (query variants, see variants.py; with both set the
+    reference builds 1 + (R+1)*S variant lists and — a latent defect, SURVEY §4 — then waits forever for
+    (R+1)*(S+1) progress ticks; the variant lists are reproduced, the hang is not).
     """
     comp = config["comparison"]
     rotations, scales = comp.get("rotations"), comp.get("scales")
-    if rotations is not None or scales is not None:
-        raise NotImplementedError(
-            "rotation/scale variants of the query maps (similarity.py:230-284) are the next row (f1) of "
-            "the hot-path scope; run with rotations = scales = \"\" for now"
-        )
     scorer = scorer or default_scorer()
-    scores = scorer.score_matrix(shoemark_maps, shoeprint_maps)
+    scores = scorer.score_matrix(shoemark_maps, shoeprint_maps, rotations=rotations, scales=scales)
     ranks = scorer.ranks(scores, matching_pairs)
     if progress:
         for i, r in enumerate(ranks):

@@ -162,3 +162,37 @@ def check_variant_accumulate(scorer):
     mat = scorer.score_matrix([a], [1.0 - a])
     ref = oracle.similarity_matrix([a], [1.0 - a], precise=True)
     np.testing.assert_allclose(mat, ref, atol=TIGHT)
+
+
+def check_variants(scorer):
+    """f1: rotated / scaled query variants are bit-identical to Pillow's (golden from the real reference),
+    and the running-max matrix / ranks over variants match the reference."""
+    from shoeprint_image_retrieval_amd.variants import VariantBuilder
+
+    z = np.load(os.path.join(GOLDEN, "variants.npz"))
+    nq, ng, c, h, w, seed = (int(v) for v in z["shape"])
+    q, g, m = synth.dataset(seed, nq, ng, c, h, w)
+    dev = scorer.dev
+    vb = VariantBuilder(scorer.lib, dev)
+    qd = dev.to_device(np.stack(q))
+    for r in (-15, 3, 180):
+        np.testing.assert_array_equal(dev.to_host(vb.rotate(qd, r)), z[f"rot_{r}"])
+    for sc in (1.02, 1.08, 0.9):
+        np.testing.assert_array_equal(dev.to_host(vb.scale(qd, sc)), z[f"scale_{sc}"])
+    mat = scorer.score_matrix(q, g, rotations=[-15, 3, 180])
+    np.testing.assert_allclose(mat, z["matrix_rot"], atol=TIGHT, rtol=0)
+    np.testing.assert_array_equal(similarity.compare_maps(q, g, m, _cfg(rot=[-15, 3, 180]), scorer=scorer), z["ranks_rot"])
+    np.testing.assert_array_equal(similarity.compare_maps(q, g, m, _cfg(sc=[1.02, 1.08]), scorer=scorer), z["ranks_scale"])
+    # both set: 1 + (R+1)*S variant lists, against the oracle (which drives real Pillow)
+    rot, sca = [9, 180], [1.08, 0.9]
+    assert len(vb.variants(qd, rot, sca)) == 1 + 3 * 2
+    both = scorer.score_matrix(q, g, rotations=rot, scales=sca)
+    ref = oracle.similarity_matrix(q, g, rotations=rot, scales=sca, precise=True)
+    np.testing.assert_allclose(both, ref, atol=TIGHT, rtol=0)
+    # square maps: 90 / 270 are exact transposes in Pillow
+    from PIL import Image
+    sq = np.stack([synth.gallery_features(3, i, 2, 12, 12) for i in range(2)])
+    sd = dev.to_device(sq)
+    for r in (90, 270, 45, -90):
+        want = np.stack([[np.array(Image.fromarray(ch).rotate(r)) for ch in item] for item in sq])
+        np.testing.assert_array_equal(dev.to_host(vb.rotate(sd, r)), want)

@@ -55,6 +55,10 @@ def test_emu_synth_twin(scorer):
     pc.check_synth_twin(scorer, emu_library())
 
 
+def test_emu_query_variants(scorer):
+    pc.check_variants(scorer)
+
+
 def test_emu_accumulate_and_floor(scorer):
     pc.check_variant_accumulate(scorer)
 

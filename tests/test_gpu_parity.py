@@ -75,6 +75,10 @@ def test_synth_twin(scorer, lib):
     pc.check_synth_twin(scorer, lib)
 
 
+def test_query_variants(scorer):
+    pc.check_variants(scorer)
+
+
 def test_accumulate_and_floor(scorer):
     pc.check_variant_accumulate(scorer)
 
