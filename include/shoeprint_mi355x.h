@@ -56,7 +56,8 @@ enum spr_dtype { SPR_F32 = 0, SPR_F16 = 1, SPR_BF16 = 2 };
 enum spr_ncc_method {
   SPR_NCC_AUTO = 0,   /* FFT when the padded maps fit the LDS-resident FFT, else direct */
   SPR_NCC_FFT = 1,    /* frequency-domain correlation, LDS-resident inverse 2-D FFT per channel */
-  SPR_NCC_DIRECT = 2  /* sliding-window correlation in LDS (any shape that fits LDS) */
+  SPR_NCC_DIRECT = 2, /* sliding-window correlation in LDS (any shape that fits LDS) */
+  SPR_NCC_FFT_POW2 = 3 /* as SPR_NCC_FFT but restricted to power-of-two grids (A/B and fallback for the 3*2^k grids) */
 };
 
 typedef void* spr_stream_t;

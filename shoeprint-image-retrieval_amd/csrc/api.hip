@@ -94,7 +94,8 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
     set_error("spr_ncc_plan_create: unknown dtype %d", shape->dtype);
     return SPR_ERR_ARG;
   }
-  if (shape->method != SPR_NCC_AUTO && shape->method != SPR_NCC_FFT && shape->method != SPR_NCC_DIRECT) {
+  if (shape->method != SPR_NCC_AUTO && shape->method != SPR_NCC_FFT && shape->method != SPR_NCC_DIRECT &&
+      shape->method != SPR_NCC_FFT_POW2) {
     set_error("spr_ncc_plan_create: unknown method %d", shape->method);
     return SPR_ERR_ARG;
   }
@@ -111,8 +112,8 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   }
   int method = 0;
   NccGeom gf = g, gd = g;
-  const bool fft_ok = fft_geometry(gf), direct_ok = direct_geometry(gd);
-  if (shape->method == SPR_NCC_FFT) {
+  const bool fft_ok = fft_geometry(gf, shape->method == SPR_NCC_FFT_POW2), direct_ok = direct_geometry(gd);
+  if (shape->method == SPR_NCC_FFT || shape->method == SPR_NCC_FFT_POW2) {
     if (!fft_ok) { set_error("FFT method: no instantiated LDS-resident grid fits query %dx%d vs gallery %dx%d", g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
     method = SPR_NCC_FFT;
   } else if (shape->method == SPR_NCC_DIRECT) {

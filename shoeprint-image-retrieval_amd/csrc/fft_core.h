@@ -160,37 +160,53 @@ struct Dft {
   }
 };
 
-// LDS image of one group's exchange: E rows of TG (+1 pad) complex values.  The +1 keeps the strided
-// stage-2 reads off a single bank; the group size is rounded up so that the 16/TG groups sharing one
-// 16-lane ds_write_b64 slice (and the groups sharing a 32-lane ds_read_b64 half) start on different banks:
-// group stride == TG (mod 16) complex elements.
+// ---------------------------------------------------------------------------------------------------
+// Group FFT, general form: length N = E * TG on TG consecutive lanes with E complex registers each.
+//
+//   input    x[m]      = data[t + TG*m]                                  m = 0..E-1
+//   stage 1  length-E DFT over m (registers), then twiddle w_N^(DIR*t*p)  -> U_t[p], p = 0..E-1
+//   stage 2  E sub-transforms of length TG over the lanes; lane t owns p = t + TG*pp (pp = 0..SPL-1,
+//            SPL = ceil(E/TG); lanes whose p >= E idle for that pp — e.g. E = 12, TG = 16 uses 12 of 16
+//            lanes in stage 2, E = 12, TG = 8 runs 8 + 4)
+//   output   y[pp][s]  = result[(t + TG*pp) + E*s]                       s = 0..TG-1
+//
+// The all-to-all between the stages goes through LDS in SPL phases: in phase pp every lane writes the
+// (up to TG) values with p in [TG*pp, TG*pp + TG) and the owning lanes read one row of TG values, so the
+// exchange image of a group is only min(E,TG) x (TG+1) complex values (not E x TG), and the stage-2
+// DFT of phase pp can overlap the LDS traffic of phase pp+1 of the other wave on the SIMD.
+// E need not be a multiple of TG: that is what admits the 3*2^k grids (192 = 12*16, 96 = 12*8).
 template <int E, int TG>
-struct GroupFftLds {
-  static constexpr int kRow = TG + 1;
-  static constexpr int kRaw = E * kRow;
+struct GroupFft {
+  static constexpr int N = E * TG;
+  static constexpr int SPL = (E + TG - 1) / TG;
+  // rows of the exchange image = values of p exchanged per phase: one stage-2 sub-transform set (TG rows)
+  // when E >= TG; when E < TG (a single set, E rows) at most 8 rows at a time to keep the image small
+  static constexpr int PH = E >= TG ? TG : (E > 8 ? 8 : E);
+  static constexpr int NPH = (E + PH - 1) / PH;  // phases
+  static constexpr int kRow = TG + 1;         // +1: the strided row reads of stage 2 spread over the banks
+  static constexpr int kRaw = PH * kRow;
+  // group stride == TG (mod 16): the 16/TG groups sharing a 16-lane ds_write_b64 slice start on different banks
   static constexpr int kGroupElems = kRaw + ((TG % 16) - (kRaw % 16) + 16) % 16;
   static constexpr int block_elems(int threads) { return (threads / TG) * kGroupElems; }
+  static __host__ __device__ constexpr int in_index(int t, int m) { return t + TG * m; }
+  static __host__ __device__ constexpr bool out_valid(int t, int pp) { return t + TG * pp < E; }
+  static __host__ __device__ constexpr int out_index(int t, int pp, int s) { return (t + TG * pp) + E * s; }
 };
 
-// Per-lane twiddles w_N^(DIR*t*p), p = 0..E-1, from the forward table tw[k] = exp(-2*pi*i*k/N).
-template <int E, int TG, int DIR>
-__device__ __forceinline__ void load_twiddles(cf (&twr)[E], const cf* __restrict__ tw, int t) {
-#pragma unroll
-  for (int p = 0; p < E; ++p) {
-    const cf w = tw[t * p];
-    twr[p] = DIR > 0 ? cconj(w) : w;
-  }
-}
-
-// The transform described at the top of this file.  `xbuf` is this group's exchange image
-// (GroupFftLds<E,TG>::kGroupElems complex values of LDS); every lane of the wave must call this
-// function together.  The image may be reused as soon as the function returns.
-// Twiddle source for group_fft: registers (loaded once per kernel) ...
+// Twiddle sources: registers (w[p] = w_N^(DIR*t*p), loaded once per kernel) ...
 template <int E>
 struct RegTwiddles {
   cf w[E];
   __device__ __forceinline__ cf get(int p) const { return w[p]; }
 };
+template <int E, int TG, int DIR>
+__device__ __forceinline__ void load_twiddles(RegTwiddles<E>& r, const cf* __restrict__ tw, int t) {
+#pragma unroll
+  for (int p = 0; p < E; ++p) {
+    const cf w = tw[t * p];  // forward table tw[k] = exp(-2*pi*i*k/N), t*p < N
+    r.w[p] = DIR > 0 ? cconj(w) : w;
+  }
+}
 // ... or a table in LDS laid out [p][t] = w_N^(DIR*t*p) (E rows of TG entries), read at use: saves 2E VGPRs
 // per lane, and the TG lanes of a group read TG consecutive entries (conflict-free, all groups broadcast).
 template <int TG>
@@ -200,58 +216,40 @@ struct LdsTwiddles {
   __device__ __forceinline__ cf get(int p) const { return table[p * TG + t]; }
 };
 
-template <int E, int TG, int DIR, class Tw>
-__device__ __forceinline__ void group_fft_tw(cf (&x)[E], int t, const Tw& tw, cf* xbuf) {
-  constexpr int PP = E / TG;
-  static_assert(E % TG == 0, "E must be a multiple of TG");
-  constexpr int kRow = GroupFftLds<E, TG>::kRow;
+// Every lane of the wave must call this together; `xbuf` is the group's exchange image
+// (GroupFft<E,TG>::kGroupElems complex values); it may be reused as soon as the function returns.
+template <int E, int TG, int DIR, class Tw, int SPL>
+__device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, const Tw& tw, cf* xbuf) {
+  using G = GroupFft<E, TG>;
+  static_assert(SPL == G::SPL, "y must be [GroupFft<E,TG>::SPL][TG]");
   Dft<E, DIR>::run(x);
+  if constexpr (E < TG) {
 #pragma unroll
-  for (int p = 0; p < E; ++p) {
-    const cf v = p == 0 ? x[0] : cmul(x[p], tw.get(p));
-    xbuf[p * kRow + t] = v;
+    for (int tt = 0; tt < TG; ++tt) y[0][tt] = cmake(0.0f, 0.0f);  // lanes t >= E own no sub-transform
   }
-  wave_sync();
-  cf y[PP][TG];
 #pragma unroll
-  for (int pp = 0; pp < PP; ++pp) {
+  for (int ph = 0; ph < G::NPH; ++ph) {
 #pragma unroll
-    for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[(t + TG * pp) * kRow + tt];
+    for (int r = 0; r < G::PH; ++r) {
+      const int p = G::PH * ph + r;
+      if (p < E) xbuf[r * G::kRow + t] = p == 0 ? x[0] : cmul(x[p], tw.get(p));
+    }
+    wave_sync();
+    constexpr int kE = E, kTG = TG;
+    const int pp = kE >= kTG ? ph : 0;        // the sub-transform set this phase feeds
+    const int row = t + TG * pp - G::PH * ph;  // image row holding this lane's p = t + TG*pp, if in this phase
+    const bool have = (E % TG == 0) || (row >= 0 && row < G::PH && t + TG * pp < E);
+    if (have) {
+#pragma unroll
+      for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[row * G::kRow + tt];
+    } else if (kE >= kTG) {
+#pragma unroll
+      for (int tt = 0; tt < TG; ++tt) y[pp][tt] = cmake(0.0f, 0.0f);
+    }
+    wave_sync();  // the image is rewritten by the next phase / the next call
+    if constexpr (E >= TG) Dft<TG, DIR>::run(y[ph]);
   }
-  wave_sync();
-#pragma unroll
-  for (int pp = 0; pp < PP; ++pp) {
-    Dft<TG, DIR>::run(y[pp]);
-#pragma unroll
-    for (int s = 0; s < TG; ++s) x[pp + PP * s] = y[pp][s];
-  }
-}
-
-template <int E, int TG, int DIR>
-__device__ __forceinline__ void group_fft(cf (&x)[E], int t, const cf (&twr)[E], cf* xbuf) {
-  constexpr int PP = E / TG;
-  static_assert(E % TG == 0, "E must be a multiple of TG");
-  constexpr int kRow = GroupFftLds<E, TG>::kRow;
-  Dft<E, DIR>::run(x);
-#pragma unroll
-  for (int p = 0; p < E; ++p) {
-    const cf v = p == 0 ? x[0] : cmul(x[p], twr[p]);
-    xbuf[p * kRow + t] = v;
-  }
-  wave_sync();
-  cf y[PP][TG];
-#pragma unroll
-  for (int pp = 0; pp < PP; ++pp) {
-#pragma unroll
-    for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[(t + TG * pp) * kRow + tt];
-  }
-  wave_sync();
-#pragma unroll
-  for (int pp = 0; pp < PP; ++pp) {
-    Dft<TG, DIR>::run(y[pp]);
-#pragma unroll
-    for (int s = 0; s < TG; ++s) x[pp + PP * s] = y[pp][s];
-  }
+  if constexpr (E < TG) Dft<TG, DIR>::run(y[0]);
 }
 
 }  // namespace spr

@@ -14,9 +14,13 @@
 //     -> inverse row FFTs, two rows per complex transform (rows are real) -> multiply by the
 //     1/sigma map -> accumulate the channel sum in registers -> final wave/LDS max-reduction.
 //
-// All FFTs are LDS/register resident (fft_core.h): the pair kernel's only HBM/L2 traffic is the two
-// half-spectra and the 1/sigma map of the current channel, laid out in exactly the lane/register order
-// the kernel consumes (fully coalesced 8/16-byte loads).
+// Grids are 2^k or 3*2^k per axis (fft_core.h GroupFft): the VGG16 conv3_3 maps of a 512x256 print
+// (124x60 after the crop) need >= 186 x 90 and run on 192 x 96 — 56 % of the 256 x 128 power-of-two
+// grid in bytes, flops and LDS, which also lets two 256-lane workgroups share a CU.
+//
+// All FFTs are LDS/register resident: the pair kernel's only HBM/L2 traffic is the two half-spectra
+// and the 1/sigma map of the current channel, laid out in exactly the lane/register order the kernel
+// consumes (fully coalesced 16-byte loads).
 //
 // Half-spectrum bookkeeping (rows are real => X[k1][nw-k2] = conj(X[-k1][k2])):
 //   columns k2 = 0 .. nw/2 are stored; the pair kernel runs nw/2 column transforms, the first of
@@ -27,44 +31,59 @@
 namespace spr {
 namespace {
 
-// NT = work-items per workgroup of the PAIR kernel (the prep kernel always runs kThreads and
-// writes the prepared data in the pair kernel's lane order).
-template <int EH_, int TGH_, int EW_, int TGW_, int NT_ = kThreads>
+// EH x TGH: column transforms (length nh), EW x TGW: row transforms (length nw); NT = work-items per
+// workgroup of the PAIR kernel (the prep kernel always runs kThreads and writes the prepared data in the
+// pair kernel's lane order); KWA / RRA: the tuned variant's kept outputs per row sub-transform and row
+// rounds (the general variant keeps everything: KW = TGW, RR = all row pairs of the grid).
+template <int EH_, int TGH_, int EW_, int TGW_, int NT_, int KWA_, int RRA_>
 struct Cfg {
   static constexpr int EH = EH_, TGH = TGH_, EW = EW_, TGW = TGW_, NT = NT_;
+  using GH = GroupFft<EH, TGH>;
+  using GW = GroupFft<EW, TGW>;
   static constexpr int NH = EH * TGH, NW = EW * TGW;
   static constexpr int CPR = NT / TGH;  // columns per column-pass round of the pair kernel
   static constexpr int PPR = NT / TGW;  // row pairs per row-pass round of the pair kernel
-  static constexpr int PPW = EW / TGW;
-  static constexpr int COLS = NW / 2;   // columns of the intermediate image R (column nw/2 rides in column 0)
-  static constexpr int RC = (NW / 2 + CPR - 1) / CPR;  // column rounds per channel in the pair kernel
+  static constexpr int COLS = NW / 2;   // columns of the intermediate image (column nw/2 rides in column 0)
+  static constexpr int RC = (COLS + CPR - 1) / CPR;  // column rounds per channel
+  static constexpr int KW_A = KWA_, RR_A = RRA_;
+  static constexpr int KW_B = TGW, RR_B = ((NH + 1) / 2 + PPR - 1) / PPR;
+  static_assert(EH % 2 == 0 && EW % 2 == 0, "register pairs are loaded with 16-byte accesses");
   static constexpr int xbuf_elems(int threads) {
-    return GroupFftLds<EH, TGH>::block_elems(threads) > GroupFftLds<EW, TGW>::block_elems(threads)
-               ? GroupFftLds<EH, TGH>::block_elems(threads)
-               : GroupFftLds<EW, TGW>::block_elems(threads);
+    return GH::block_elems(threads) > GW::block_elems(threads) ? GH::block_elems(threads) : GW::block_elems(threads);
   }
-  // The intermediate image is stored TRANSPOSED: RT[j][n1], column j of the half spectrum, row n1, with a
-  // row stride == 8 (mod 32) complex values.  Column transforms then write 16 consecutive values per
-  // 16-lane slice with compile-time offsets, and a row-pair lane reads (row 2pr, row 2pr+1) of one column
-  // as a single 16-byte access; with that stride the four 8-lane groups of every ds_read_b128 lane group
-  // cover all 64 banks exactly once.
-  static constexpr int rt_stride(int r_rows) { return r_rows + ((8 - r_rows % 32) + 32) % 32; }
+  // Position of spectrum element (column j < COLS, k1) in a channel's prepared data: the pair kernel's
+  // lane (group j % CPR, lane-in-group k1 % TGH) loads registers (2mm, 2mm+1), m = k1 / TGH, of column
+  // round j / CPR with one 16-byte access.
+  static __host__ __device__ constexpr int spec_index(int j, int k1) {
+    return (((j / CPR) * (EH / 2) + (k1 / TGH) / 2) * NT + (j % CPR) * TGH + (k1 % TGH)) * 2 + ((k1 / TGH) & 1);
+  }
+  static constexpr int kNyqOffset = RC * EH * NT;  // column nw/2 follows in natural k1 order
+  static constexpr int kSpecPerChan = kNyqOffset + NH;
 };
 
+// The intermediate image is stored TRANSPOSED: RT[j][n1], column j of the half spectrum, row n1, with a
+// row stride == 8 (mod 32) complex values.  Column transforms then write consecutive values per group with
+// compile-time offsets, and a row-pair lane reads (row 2pr, row 2pr+1) of one column as a single 16-byte
+// access; with that stride the four 8-lane groups of every ds_read_b128 lane group cover all 64 banks once.
+inline int rt_stride(int r_rows) { return r_rows + ((8 - r_rows % 32) + 32) % 32; }
+
 // ============================================================================================
-// Forward (prep) kernel.  grid = (channels, n_items)
+// Forward (prep) kernel.  grid = (channels, n_items), kThreads lanes
 // ============================================================================================
 template <class C>
 __global__ void __launch_bounds__(kThreads)
 prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                 size_t item_bytes, const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned x0_off,
-                unsigned f_off, unsigned xbuf_off, int f_stride) {
+                unsigned f_off, unsigned xbuf_off, unsigned zbuf_off, int f_stride) {
+  using GH = typename C::GH;
+  using GW = typename C::GW;
   unsigned char* lds = dyn_lds();
   double* red = reinterpret_cast<double*>(lds);
   float* x0 = reinterpret_cast<float*>(lds + x0_off);
   double* sat = reinterpret_cast<double*>(lds + f_off);  // dead before F is written
   cf* F = reinterpret_cast<cf*>(lds + f_off);
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
+  cf* zbuf = reinterpret_cast<cf*>(lds + zbuf_off);
   const int tid = static_cast<int>(threadIdx.x);
   const int c = static_cast<int>(blockIdx.x);
   const size_t item = blockIdx.y;
@@ -72,7 +91,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   const int raw_h = is_query ? g.q_h : g.g_h, raw_w = is_query ? g.q_w : g.g_w;
 
   unsigned char* item_base = prepared + item * item_bytes;
-  cf* spec = reinterpret_cast<cf*>(item_base) + static_cast<size_t>(c) * g.spec_per_chan;
+  cf* spec = reinterpret_cast<cf*>(item_base) + static_cast<size_t>(c) * C::kSpecPerChan;
 
   load_centred(maps, (item * g.channels + c) * static_cast<size_t>(raw_h) * raw_w, raw_w, g.crop, h, w, g.dtype, x0,
                red);
@@ -81,17 +100,17 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     scale = template_scale(x0, h * w, red) * (1.0f / (static_cast<float>(C::NH) * static_cast<float>(C::NW)));
   } else {
     // 1/sigma map in the pair kernel's register order; slots no pixel maps to stay 0.
-    float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan) +
+    float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
                  static_cast<size_t>(c) * g.inv_per_chan;
     for (int i = tid; i < g.inv_per_chan; i += kThreads) inv[i] = 0.0f;
     __syncthreads();
-    const int nv = C::PPW * g.keep_w * 2;
+    const int nv = g.nv;
     inv_sigma_map(x0, h, w, g.th, g.tw, sat, [&](int i, float v) {
       const int n1 = i / w, n2 = i - n1 * w;
       const int pr = n1 >> 1, ab = n1 & 1;
       const int rr = pr / C::PPR, giw = pr - rr * C::PPR;
-      const int p = n2 % C::EW, s = n2 / C::EW;
-      const int pp = p / C::TGW, t = p - pp * C::TGW;
+      const int p = n2 % C::EW, s = n2 / C::EW;       // output n2 = p + EW*s of the row transform
+      const int pp = p / C::TGW, t = p - pp * C::TGW;  // owned by lane t of the group, sub-transform pp
       const int e2 = (pp * g.keep_w + s) * 2 + ab;
       const int lane = giw * C::TGW + t;
       inv[((rr * (nv / 4) + (e2 >> 2)) * C::NT + lane) * 4 + (e2 & 3)] = v;
@@ -101,39 +120,39 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   // ---- row pass: two real rows per complex transform of length NW -------------------------------
   {
     const int giw = tid / C::TGW, t = tid - giw * C::TGW;
-    cf twr[C::EW];
+    RegTwiddles<C::EW> twr;
     load_twiddles<C::EW, C::TGW, -1>(twr, tw_w, t);
-    cf* gbuf = xbuf + giw * GroupFftLds<C::EW, C::TGW>::kGroupElems;
+    cf* gbuf = xbuf + giw * GW::kGroupElems;
+    cf* zb = zbuf + giw * C::NW;
     const int pairs = (h + 1) / 2;
     constexpr int kPairsPerRound = kThreads / C::TGW;
     const int rounds = ceil_div(pairs, kPairsPerRound);
     for (int rr = 0; rr < rounds; ++rr) {
       const int pr = rr * kPairsPerRound + giw;
       const int ra = 2 * pr, rb = ra + 1;
-      cf x[C::EW];
+      cf x[C::EW], y[GW::SPL][C::TGW];
 #pragma unroll
       for (int m = 0; m < C::EW; ++m) {
-        const int n2 = t + C::TGW * m;
+        const int n2 = GW::in_index(t, m);
         const bool in = n2 < w;
         x[m].x = (in && ra < h) ? x0[ra * w + n2] * scale : 0.0f;
         x[m].y = (in && rb < h) ? x0[rb * w + n2] * scale : 0.0f;
       }
-      group_fft<C::EW, C::TGW, -1>(x, t, twr, gbuf);
+      group_fft<C::EW, C::TGW, -1>(x, y, t, twr, gbuf);
       // publish Z[k] for the group, then split the two real rows:  Xa = (Z[k] + conj Z[-k])/2,
       // Xb = (Z[k] - conj Z[-k])/(2i)
 #pragma unroll
-      for (int m = 0; m < C::EW; ++m) gbuf[t + C::TGW * m] = x[m];
+      for (int pp = 0; pp < GW::SPL; ++pp)
+#pragma unroll
+        for (int s = 0; s < C::TGW; ++s)
+          if (GW::out_valid(t, pp)) zb[GW::out_index(t, pp, s)] = y[pp][s];
       wave_sync();
       if (pr < pairs) {
-#pragma unroll
-        for (int m = 0; m < C::EW; ++m) {
-          const int k = t + C::TGW * m;
-          if (k <= C::NW / 2) {
-            const cf zk = gbuf[k];
-            const cf zm = gbuf[(C::NW - k) & (C::NW - 1)];
-            F[ra * f_stride + k] = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-            F[rb * f_stride + k] = cmake(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
-          }
+        for (int k = t; k <= C::NW / 2; k += C::TGW) {
+          const cf zk = zb[k];
+          const cf zm = zb[k == 0 ? 0 : C::NW - k];
+          F[ra * f_stride + k] = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+          F[rb * f_stride + k] = cmake(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
         }
       }
       wave_sync();
@@ -144,42 +163,39 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   // ---- column pass: nw/2 + 1 columns of length NH ----------------------------------------------
   {
     const int gi = tid / C::TGH, t = tid - gi * C::TGH;
-    cf twr[C::EH];
+    RegTwiddles<C::EH> twr;
     load_twiddles<C::EH, C::TGH, -1>(twr, tw_h, t);
-    cf* gbuf = xbuf + gi * GroupFftLds<C::EH, C::TGH>::kGroupElems;
+    cf* gbuf = xbuf + gi * GH::kGroupElems;
     const int rows_f = 2 * ((h + 1) / 2);
     const int cy = g.th / 2, cx = g.tw / 2;
     constexpr int kColsPerRound = kThreads / C::TGH;
-    const int rounds = ceil_div(C::NW / 2, kColsPerRound);
+    const int rounds = ceil_div(C::COLS, kColsPerRound);
     for (int rc = 0; rc <= rounds; ++rc) {
       const bool nyq = rc == rounds;
-      const int j = nyq ? C::NW / 2 : rc * kColsPerRound + gi;
-      const bool active = nyq ? gi == 0 : j < C::NW / 2;
-      cf x[C::EH];
+      const int j = nyq ? C::COLS : rc * kColsPerRound + gi;
+      const bool active = nyq ? gi == 0 : j < C::COLS;
+      cf x[C::EH], y[GH::SPL][C::TGH];
 #pragma unroll
       for (int m = 0; m < C::EH; ++m) {
-        const int n1 = t + C::TGH * m;
+        const int n1 = GH::in_index(t, m);
         x[m] = (active && n1 < rows_f) ? F[n1 * f_stride + j] : cmake(0.0f, 0.0f);
       }
-      group_fft<C::EH, C::TGH, -1>(x, t, twr, gbuf);
+      group_fft<C::EH, C::TGH, -1>(x, y, t, twr, gbuf);
       if (active) {
         cf wx = cmake(1.0f, 0.0f);
-        if (is_query) wx = tw_w[(cx * j) & (C::NW - 1)];
+        if (is_query) wx = tw_w[(cx * j) % C::NW];
 #pragma unroll
-        for (int m = 0; m < C::EH; ++m) {
-          cf v = x[m];
-          if (is_query) {
-            const int k1 = t + C::TGH * m;
-            const cf wy = tw_h[(cy * k1) & (C::NH - 1)];
-            v = cmul(cmul(cconj(v), wy), wx);  // conj(A) * w^(cy k1) * w^(cx k2): centre shift folded in
-          }
-          if (nyq) {
-            spec[static_cast<size_t>(g.rounds_c) * C::EH * C::NT + m * C::TGH + t] = v;
-          } else {  // the pair kernel's (round, lane) for column j
-            // element (round prc, register m, lane plane): registers 2mm, 2mm+1 of a lane are adjacent
-            // so that the pair kernel loads them with one 16-byte access
-            const int prc = j / C::CPR, plane = (j - prc * C::CPR) * C::TGH + t;
-            spec[((static_cast<size_t>(prc) * (C::EH / 2) + (m >> 1)) * C::NT + plane) * 2 + (m & 1)] = v;
+        for (int pp = 0; pp < GH::SPL; ++pp) {
+          if (!GH::out_valid(t, pp)) continue;
+#pragma unroll
+          for (int s = 0; s < C::TGH; ++s) {
+            const int k1 = GH::out_index(t, pp, s);
+            cf v = y[pp][s];
+            if (is_query) {
+              const cf wy = tw_h[(cy * k1) % C::NH];
+              v = cmul(cmul(cconj(v), wy), wx);  // conj(A) * w^(cy k1) * w^(cx k2): centre shift folded in
+            }
+            spec[nyq ? C::kNyqOffset + k1 : C::spec_index(j, k1)] = v;
           }
         }
       }
@@ -190,27 +206,32 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
 // ============================================================================================
 // Pair kernel.  One workgroup per (query, gallery) pair, looping over the channels.
 //
-// Memory-latency structure (the kernel streams ~300 KB of spectra + 1/sigma per pair and channel, far
-// more than it can keep in LDS, so everything is register-prefetched one step ahead):
+// Memory-latency structure (the kernel streams ~180-300 KB of spectra + 1/sigma per pair and channel,
+// far more than it can keep in LDS, so everything is register-prefetched ahead of use):
 //   * the column pass is a flat sequence of "units" (channel c, column round rc); the two half-spectra
-//     of unit u+1 are loaded (16-byte loads, lane-ordered layout) before unit u is computed;
-//   * the 1/sigma slice and the Nyquist column (k2 = nw/2: one complex value per lane, staged through
-//     a small LDS buffer for the 16 lanes that consume it) of channel c+1 are loaded during channel c;
-//   * no wait is placed by hand: loads are issued a full unit early and the compiler's counted
-//     s_waitcnt sits at the first use.
+//     of a later unit are loaded (16-byte loads, lane-ordered layout) before the current one is computed:
+//     with PF == RC there is one buffer per round, refilled right after it is consumed (a full channel of
+//     lead), with PF == 1 a single buffer holds the next unit (fewer registers);
+//   * the 1/sigma slice is requested at the start of a channel's row pass and used at its end, the
+//     Nyquist column (k2 = nw/2: staged through a small LDS buffer for the lanes of column group 0) of
+//     channel c+1 is loaded during channel c;
+//   * no wait is placed by hand: loads are issued early and the compiler's counted s_waitcnt sits at
+//     the first use.
 // Pair -> workgroup mapping: 1-D grid in tiles of 16 queries x 16 gallery items.  Workgroups are dealt
 // round-robin over the 8 XCDs, so workgroup w of a tile (w % 8 = XCD group) takes a 4-query x 8-gallery
 // sub-tile: the 32 workgroups sharing one L2 touch only 4 + 8 distinct spectra per channel.
 // ============================================================================================
 constexpr int kTileQ = 16, kTileG = 16;
 
-template <class C, int RR, int KW>
+template <class C, int RR, int KW, int PF>
 __global__ void __launch_bounds__(C::NT, 2)
 pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
                 const unsigned char* __restrict__ pg, size_t g_item_bytes, int nq, int ng, float* __restrict__ scores,
                 long long ld, long long col0, int accumulate, float* __restrict__ maps_out,
                 const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off,
                 unsigned nyq_off_lds) {
+  using GH = typename C::GH;
+  using GW = typename C::GW;
   // ---- which pair ------------------------------------------------------------------------------
   const int tiles_g = ceil_div(ng, kTileG);
   const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
@@ -227,24 +248,25 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
   cf* nyq = reinterpret_cast<cf*>(lds + nyq_off_lds);  // [0, NH): gallery column nw/2, [NH, 2NH): query's
   const int tid = static_cast<int>(threadIdx.x);
-  constexpr int NV = C::PPW * KW * 2;       // accumulators per lane and row round
-  constexpr int RC = C::RC;                 // column rounds per channel
-  constexpr int H2 = C::EH / 2;             // 16-byte loads per operand and unit
+  constexpr int NVR = GW::SPL * KW * 2;          // accumulators per lane and row round ...
+  constexpr int NV = (NVR + 3) / 4 * 4;          // ... padded to whole 16-byte loads of 1/sigma
+  constexpr int RC = C::RC;                      // column rounds per channel
+  constexpr int H2 = C::EH / 2;                  // 16-byte loads per operand and unit
   constexpr int NYQ = (2 * C::NH + C::NT - 1) / C::NT;  // Nyquist values prefetched per lane
+  static_assert(PF == 1 || PF == RC, "prefetch depth: one unit or one buffer per round");
 
   const unsigned char* q_item = pq + static_cast<size_t>(qi) * q_item_bytes;
   const unsigned char* g_item = pg + static_cast<size_t>(gi_item) * g_item_bytes;
   const cf* qspec = reinterpret_cast<const cf*>(q_item);
   const cf* gspec = reinterpret_cast<const cf*>(g_item);
-  const float* ginv = reinterpret_cast<const float*>(g_item + sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan);
-  const size_t nyq_off = static_cast<size_t>(RC) * C::EH * C::NT;
+  const float* ginv = reinterpret_cast<const float*>(g_item + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan);
   const int last_c = g.channels - 1;
-
   const int tid0 = tid;
-  // inverse twiddle tables w^(+k) in LDS (read at use: keeps 2*(EH+EW) VGPRs free for the prefetch)
+
+  // inverse twiddle tables w^(+t*p), [p][t], in LDS (read at use: keeps 2*(EH+EW) VGPRs free)
   cf* twt_h = nyq + 2 * C::NH;
   cf* twt_w = twt_h + C::NH;
-  for (int k = tid; k < C::NH; k += C::NT) twt_h[k] = cconj(tw_h[(k / C::TGH) * (k % C::TGH)]);  // [p][t]
+  for (int k = tid; k < C::NH; k += C::NT) twt_h[k] = cconj(tw_h[(k / C::TGH) * (k % C::TGH)]);
   for (int k = tid; k < C::NW; k += C::NT) twt_w[k] = cconj(tw_w[(k / C::TGW) * (k % C::TGW)]);
 
   float acc[RR][NV];
@@ -253,17 +275,18 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
 #pragma unroll
     for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
   const int pairs = g.r_rows / 2;
-  const int rs = g.r_stride;  // row stride of the transposed image RT[j][n1]
-  const int m_keep = g.r_rows / C::TGH;  // registers of a column transform whose rows are kept (r_rows = EH*sh)
+  const int rs = g.r_stride;                    // row stride of the transposed image RT[j][n1]
+  const int s_full = g.r_rows / C::EH;          // column outputs p + EH*s with s < s_full are rows < r_rows ...
+  const int p_part = g.r_rows - s_full * C::EH;  // ... for every p; at s == s_full only p < p_part
 
   // ---- prefetch state --------------------------------------------------------------------------
-  float4 nxt[RC][2 * H2];  // one buffer per column round: H2 x (2 complex of G), H2 x (2 complex of Q)
+  float4 nxt[PF][2 * H2];  // H2 x (2 complex of G), H2 x (2 complex of Q) per buffer
   float4 inv_nxt[RR][NV / 4];
   cf nyq_nxt[NYQ];
   auto issue_unit = [&](int c, int rc, float4 (&buf)[2 * H2]) {
     c = c > last_c ? last_c : c;  // the one-past-the-end prefetch re-reads the last channel (never used)
-    const float4* gs4 = reinterpret_cast<const float4*>(gspec + static_cast<size_t>(c) * g.spec_per_chan);
-    const float4* qs4 = reinterpret_cast<const float4*>(qspec + static_cast<size_t>(c) * g.spec_per_chan);
+    const float4* gs4 = reinterpret_cast<const float4*>(gspec + static_cast<size_t>(c) * C::kSpecPerChan);
+    const float4* qs4 = reinterpret_cast<const float4*>(qspec + static_cast<size_t>(c) * C::kSpecPerChan);
 #pragma unroll
     for (int mm = 0; mm < H2; ++mm) {
       const size_t idx = (static_cast<size_t>(rc) * H2 + mm) * C::NT + tid;
@@ -272,7 +295,6 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
     }
   };
   auto issue_inv = [&](int c) {
-    c = c > last_c ? last_c : c;
     const float4* inv4 = reinterpret_cast<const float4*>(ginv + static_cast<size_t>(c) * g.inv_per_chan);
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr)
@@ -282,8 +304,8 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   };
   auto issue_nyq = [&](int c) {
     c = c > last_c ? last_c : c;
-    const cf* gs = gspec + static_cast<size_t>(c) * g.spec_per_chan + nyq_off;
-    const cf* qs = qspec + static_cast<size_t>(c) * g.spec_per_chan + nyq_off;
+    const cf* gs = gspec + static_cast<size_t>(c) * C::kSpecPerChan + C::kNyqOffset;
+    const cf* qs = qspec + static_cast<size_t>(c) * C::kSpecPerChan + C::kNyqOffset;
 #pragma unroll
     for (int i = 0; i < NYQ; ++i) {
       const int k = tid + i * C::NT;
@@ -299,8 +321,12 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   };
 
   issue_nyq(0);
+  if constexpr (PF == RC) {
 #pragma unroll
-  for (int rc = 0; rc < RC; ++rc) issue_unit(0, rc, nxt[rc]);
+    for (int rc = 0; rc < RC; ++rc) issue_unit(0, rc, nxt[rc]);
+  } else {
+    issue_unit(0, 0, nxt[0]);
+  }
   store_nyq();
   __syncthreads();
 
@@ -311,23 +337,26 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
     const int gr = tidv / C::TGW, tr = tidv - gr * C::TGW;  // row-pass group / lane in group
     const LdsTwiddles<C::TGH> twc{twt_h, tc};
     const LdsTwiddles<C::TGW> twr{twt_w, tr};
-    cf* cbuf = xbuf + gc * GroupFftLds<C::EH, C::TGH>::kGroupElems;
-    cf* rbuf = xbuf + gr * GroupFftLds<C::EW, C::TGW>::kGroupElems;
-    // ---- column pass: product spectrum -> inverse transforms along k1 -> R (rows < r_rows) -------
+    cf* cbuf = xbuf + gc * GH::kGroupElems;
+    cf* rbuf = xbuf + gr * GW::kGroupElems;
+    // ---- column pass: product spectrum -> inverse transforms along k1 -> RT (rows < r_rows) -------
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc) {
       const int j = rc * C::CPR + gc;
-      const bool active = j < C::NW / 2;
-      cf z[C::EH];
+      const bool active = j < C::COLS;
+      float4 (&buf)[2 * H2] = nxt[PF == RC ? rc : 0];
+      cf z[C::EH], y[GH::SPL][C::TGH];
 #pragma unroll
       for (int mm = 0; mm < H2; ++mm) {
-        const float4 a = nxt[rc][mm], b = nxt[rc][H2 + mm];
+        const float4 a = buf[mm], b = buf[H2 + mm];
         z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
         z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
       }
-      // this round's operands of the NEXT channel start flying now: a full channel (RC units) of lead
-      issue_unit(c + 1, rc, nxt[rc]);
-      if constexpr (RC * C::CPR != C::NW / 2) {  // surplus groups of the last round transform zeros
+      // operands of a later unit start flying now
+      if constexpr (PF == RC) issue_unit(c + 1, rc, buf);
+      else if (rc + 1 < RC) issue_unit(c, rc + 1, buf);
+      else issue_unit(c + 1, 0, buf);
+      if constexpr (RC * C::CPR != C::COLS) {  // surplus groups of the last round transform zeros
         if (!active) {
 #pragma unroll
           for (int m = 0; m < C::EH; ++m) z[m] = cmake(0.0f, 0.0f);
@@ -336,16 +365,22 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
       if (j == 0) {  // pack column nw/2 into the imaginary part of column 0
 #pragma unroll
         for (int m = 0; m < C::EH; ++m) {
-          const int k1 = tc + C::TGH * m;
+          const int k1 = GH::in_index(tc, m);
           z[m] = pk_add_i(z[m], cmul(nyq[k1], nyq[C::NH + k1]));
         }
       }
-      group_fft_tw<C::EH, C::TGH, +1>(z, tc, twc, cbuf);
+      group_fft<C::EH, C::TGH, +1>(z, y, tc, twc, cbuf);
       if (active) {
-        cf* col = R + j * rs + tc;
 #pragma unroll
-        for (int m = 0; m < C::EH; ++m) {
-          if (m < m_keep) col[C::TGH * m] = z[m];  // row tc + TGH*m < r_rows  <=>  m < r_rows/TGH: uniform
+        for (int pp = 0; pp < GH::SPL; ++pp) {
+          const int p = tc + C::TGH * pp;
+          if ((C::EH % C::TGH != 0) && p >= C::EH) continue;  // idle stage-2 lanes
+          cf* col = R + j * rs + p;
+#pragma unroll
+          for (int s = 0; s < C::TGH; ++s) {
+            if (s < s_full) col[C::EH * s] = y[pp][s];                       // uniform
+            else if (s == s_full && p < p_part) col[C::EH * s] = y[pp][s];   // last, partial row block
+          }
         }
       }
     }
@@ -361,50 +396,49 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
       // W[k] = Ya[k] + i*Yb[k] for k = tr + TGW*m, built from the stored half spectrum (columns 0..nw/2-1;
       // column nw/2 rides in the imaginary part of column 0).  Which form applies is a compile-time
       // property of the register index m, except for lane tr == 0 of the two registers holding k = 0, nw/2.
-      const cf* direct = R + tr * rs + 2 * pr;                // column k            (k < nw/2)
-      const cf* mirror = R + (C::TGW - tr) * rs + 2 * pr;     // column nw - k       (k > nw/2), from m = EW-1 down
-      cf wv[C::EW];
+      const cf* direct = R + tr * rs + 2 * pr;             // column k          (k < nw/2)
+      const cf* mirror = R + (C::TGW - tr) * rs + 2 * pr;  // column nw - k     (k > nw/2), from m = EW-1 down
+      cf wv[C::EW], y[GW::SPL][C::TGW];
 #pragma unroll
       for (int m = 0; m < C::EW; ++m) {
-        if constexpr (true) {
-          if (m < C::EW / 2) {
-            const float4 ab = *reinterpret_cast<const float4*>(direct + m * C::TGW * rs);
-            cf v = pk_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // Ya + i*Yb
-            if (m == 0) v = tr == 0 ? cmake(ab.x, ab.z) : v;  // k = 0: both columns real, values in .x
-            wv[m] = v;
-          } else if (m == C::EW / 2) {
-            // k = nw/2 + tr: lane 0 takes the packed Nyquist column (.y of column 0), the others column nw/2 - tr
-            const cf* src = tr == 0 ? R + 2 * pr : mirror + (C::EW - 1 - m) * C::TGW * rs;
-            const float4 ab = *reinterpret_cast<const float4*>(src);
-            wv[m] = tr == 0 ? cmake(ab.y, ab.w) : pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));
-          } else {
-            const float4 ab = *reinterpret_cast<const float4*>(mirror + (C::EW - 1 - m) * C::TGW * rs);
-            wv[m] = pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // conj(Ya) + i*conj(Yb)
-          }
+        if (m < C::EW / 2) {
+          const float4 ab = *reinterpret_cast<const float4*>(direct + m * C::TGW * rs);
+          cf v = pk_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // Ya + i*Yb
+          if (m == 0) v = tr == 0 ? cmake(ab.x, ab.z) : v;        // k = 0: both columns real, values in .x
+          wv[m] = v;
+        } else if (m == C::EW / 2) {
+          // k = nw/2 + tr: lane 0 takes the packed Nyquist column (.y of column 0), the others column nw/2 - tr
+          const cf* src = tr == 0 ? R + 2 * pr : mirror + (C::EW - 1 - m) * C::TGW * rs;
+          const float4 ab = *reinterpret_cast<const float4*>(src);
+          wv[m] = tr == 0 ? cmake(ab.y, ab.w) : pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));
+        } else {
+          const float4 ab = *reinterpret_cast<const float4*>(mirror + (C::EW - 1 - m) * C::TGW * rs);
+          wv[m] = pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // conj(Ya) + i*conj(Yb)
         }
       }
-      group_fft_tw<C::EW, C::TGW, +1>(wv, tr, twr, rbuf);
+      group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr, rbuf);
       const float* ivf = reinterpret_cast<const float*>(inv_nxt[rr]);
 #pragma unroll
-      for (int pp = 0; pp < C::PPW; ++pp) {
+      for (int pp = 0; pp < GW::SPL; ++pp) {
 #pragma unroll
         for (int s = 0; s < KW; ++s) {
-          const cf v = wv[pp + C::PPW * s];
+          const cf v = y[pp][s];  // lanes without a sub-transform pp hold zeros and their 1/sigma slots are 0
           const int e = (pp * KW + s) * 2;
           const float va = v.x * ivf[e], vb = v.y * ivf[e + 1];
           acc[rr][e] += va;
           acc[rr][e + 1] += vb;
           if (maps_out) {
-            const int n2 = tr + C::TGW * pp + C::EW * s;
+            const int n2 = GW::out_index(tr, pp, s);
             const int n1 = 2 * (rr * C::PPR + gr);
-            if (n2 < g.iw && n1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1) * g.iw + n2] = va;
-            if (n2 < g.iw && n1 + 1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1 + 1) * g.iw + n2] = vb;
+            const bool ok = GW::out_valid(tr, pp) && n2 < g.iw;
+            if (ok && n1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1) * g.iw + n2] = va;
+            if (ok && n1 + 1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1 + 1) * g.iw + n2] = vb;
           }
         }
       }
     }
     store_nyq();      // channel c+1's Nyquist column, consumed after the barrier
-    __syncthreads();  // R is rewritten by the next channel
+    __syncthreads();  // RT is rewritten by the next channel
   }
 
   // Slots outside the ih x iw map carry 1/sigma = 0 and stay 0; the score is floored at 0 anyway
@@ -427,7 +461,7 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
 // Host side: configurations, LDS layouts, dispatch
 // ============================================================================================
 struct PrepFftLds {
-  size_t x0_off, f_off, xbuf_off, total;
+  size_t x0_off, f_off, xbuf_off, zbuf_off, total;
   int f_stride;
 };
 template <class C>
@@ -439,7 +473,8 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
   l.f_stride = C::NW / 2 + 1;
   const size_t f_bytes = sizeof(cf) * static_cast<size_t>(2 * ((h + 1) / 2)) * l.f_stride;
   l.xbuf_off = align_up(l.f_off + f_bytes, 16);
-  const size_t fft_total = l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads);
+  l.zbuf_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads), 16);
+  const size_t fft_total = l.zbuf_off + sizeof(cf) * (kThreads / C::TGW) * C::NW;
   const size_t sat_total = is_query ? 0 : l.f_off + sizeof(double) * (h + 1) * (w + 1);
   l.total = fft_total > sat_total ? fft_total : sat_total;
   return l;
@@ -460,19 +495,16 @@ PairFftLds pair_fft_lds(const NccGeom& g) {
 
 // One entry per instantiated (nh, nw) grid.
 struct FftEntry {
-  int nh, nw, eh, tgh, ew, tgw, nt;
-  int rr_tight, kw_tight, rr_loose, kw_loose;
+  int nh, nw, eh, tgh, ew, tgw, nt, spl_w;
+  int kw_a, rr_a, kw_b, rr_b;
+  bool pow2;
+  int spec_per_chan;
   size_t (*prep_lds_total)(const NccGeom&, bool);
   size_t (*pair_lds_total)(const NccGeom&);
   int (*prep)(const NccGeom&, bool, const void*, int64_t, void*, const cf*, const cf*, hipStream_t);
   int (*pair)(const NccGeom&, bool, const void*, int64_t, const void*, int64_t, float*, int64_t, int64_t, int, float*,
               const cf*, const cf*, hipStream_t);
 };
-
-template <class C>
-constexpr int rr_tight() { return (C::NH / 4 + C::PPR - 1) / C::PPR; }
-template <class C>
-constexpr int rr_loose() { return (C::NH / 2 + C::PPR - 1) / C::PPR; }
 
 template <class C>
 size_t prep_lds_total_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q).total; }
@@ -489,18 +521,18 @@ int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* p
   hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads),
                      l.total, stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes, tw_h,
                      tw_w, static_cast<unsigned>(l.x0_off), static_cast<unsigned>(l.f_off),
-                     static_cast<unsigned>(l.xbuf_off), l.f_stride);
+                     static_cast<unsigned>(l.xbuf_off), static_cast<unsigned>(l.zbuf_off), l.f_stride);
   return check_launch("prep_fft_kernel");
 }
 
-template <class C, int RR, int KW>
+template <class C, int RR, int KW, int PF>
 int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
                 int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, hipStream_t stream) {
   const PairFftLds l = pair_fft_lds<C>(g);
   const int64_t tiles = static_cast<int64_t>(ceil_div(static_cast<int>(nq), kTileQ)) * ceil_div(static_cast<int>(ng), kTileG);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
                      dim3(C::NT), l.total, stream, g, static_cast<const unsigned char*>(pq),
                      prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
                      prepared_gallery_item_bytes(g, SPR_NCC_FFT), static_cast<int>(nq), static_cast<int>(ng), scores,
@@ -510,33 +542,36 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
   return check_launch("pair_fft_kernel");
 }
 
-template <class C>
-int pair_t(const NccGeom& g, bool tight, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+// tuned variant: KW_A x RR_A with PFA prefetch buffers; general variant: everything kept, one buffer
+template <class C, int PFA>
+int pair_t(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
            hipStream_t stream) {
-  if (tight)
-    return pair_launch<C, rr_tight<C>(), C::TGW / 2>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h,
-                                                     tw_w, stream);
-  return pair_launch<C, rr_loose<C>(), C::TGW>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
-                                               stream);
+  if (tuned)
+    return pair_launch<C, C::RR_A, C::KW_A, PFA>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                                 stream);
+  return pair_launch<C, C::RR_B, C::KW_B, 1>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                             stream);
 }
 
-template <class C>
+template <class C, int PFA>
 constexpr FftEntry entry() {
-  return FftEntry{C::NH,          C::NW,          C::EH,         C::TGH,       C::EW,
-                  C::TGW,         C::NT,          rr_tight<C>(), C::TGW / 2,   rr_loose<C>(),
-                  C::TGW,         prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C>};
+  return FftEntry{C::NH,   C::NW,   C::EH,   C::TGH,  C::EW,   C::TGW, C::NT, C::GW::SPL,
+                  C::KW_A, C::RR_A, C::KW_B, C::RR_B, (C::NH & (C::NH - 1)) == 0 && (C::NW & (C::NW - 1)) == 0,
+                  C::kSpecPerChan, prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C, PFA>};
 }
 
-// (E, TG) factorisations: 256 = 16*16, 128 = 16*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
+// (E, TG) factorisations: 256 = 16*16, 192 = 12*16, 128 = 16*8, 96 = 12*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
+//                 EH TGH EW TGW  NT KWA RRA      prefetch buffers of the tuned variant
 const FftEntry kEntries[] = {
-    entry<Cfg<8, 4, 4, 4>>(),      // 32 x 16
-    entry<Cfg<8, 4, 8, 4>>(),      // 32 x 32
-    entry<Cfg<8, 8, 8, 4>>(),      // 64 x 32
-    entry<Cfg<8, 8, 8, 8>>(),      // 64 x 64
-    entry<Cfg<16, 8, 8, 8>>(),     // 128 x 64
-    entry<Cfg<16, 8, 16, 8>>(),    // 128 x 128
-    entry<Cfg<16, 16, 16, 8, 512>>(),   // 256 x 128: 8 waves per workgroup (2 per SIMD), one workgroup per CU
+    entry<Cfg<8, 4, 4, 4, 256, 2, 1>, 1>(),       // 32 x 16
+    entry<Cfg<8, 4, 8, 4, 256, 2, 1>, 1>(),       // 32 x 32
+    entry<Cfg<8, 8, 8, 4, 256, 2, 1>, 1>(),       // 64 x 32
+    entry<Cfg<8, 8, 8, 8, 256, 4, 1>, 1>(),       // 64 x 64
+    entry<Cfg<16, 8, 8, 8, 256, 4, 1>, 1>(),      // 128 x 64
+    entry<Cfg<16, 8, 16, 8, 256, 4, 1>, 1>(),     // 128 x 128
+    entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),    // 192 x 96: conv3_3 of a 512x256 print; two workgroups per CU
+    entry<Cfg<16, 16, 16, 8, 512, 4, 1>, 2>(),    // 256 x 128: 8 waves per workgroup, one workgroup per CU
 };
 
 const FftEntry* find_entry(int nh, int nw) {
@@ -555,16 +590,18 @@ bool fill_geometry(NccGeom& g, const FftEntry& e) {
   g.nh = e.nh; g.nw = e.nw; g.eh = e.eh; g.tgh = e.tgh; g.ew = e.ew; g.tgw = e.tgw; g.nt = e.nt;
   const int cpr = e.nt / e.tgh, ppr = e.nt / e.tgw;
   g.rounds_c = ceil_div(e.nw / 2, cpr);
-  const bool tight = g.ih <= e.nh / 2 && g.iw <= e.nw / 2;
-  g.tight = tight ? 1 : 0;
-  g.sh = ceil_div(g.ih, e.eh);  // kept outputs per column sub-transform (<= tgh/2 when tight)
-  g.r_rows = e.eh * g.sh;
-  g.r_stride = g.r_rows + ((8 - g.r_rows % 32) + 32) % 32;  // Cfg::rt_stride
+  g.r_rows = (g.ih + 7) / 8 * 8;  // rows kept after the column pass (even; rows >= ih carry 1/sigma = 0)
+  if (g.r_rows > e.nh) g.r_rows = e.nh;
+  g.r_stride = rt_stride(g.r_rows);
   g.rounds_r = ceil_div(g.r_rows / 2, ppr);
-  g.keep_w = tight ? e.kw_tight : e.kw_loose;
-  if (g.rounds_r > (tight ? e.rr_tight : e.rr_loose)) return false;
-  g.spec_per_chan = g.rounds_c * e.eh * e.nt + e.nh;
-  g.inv_per_chan = g.rounds_r * (e.ew / e.tgw) * g.keep_w * 2 * e.nt;
+  const int kw_need = ceil_div(g.iw, e.ew);  // row outputs n2 = p + ew*s with s < kw_need cover iw
+  const bool tuned = kw_need <= e.kw_a && g.rounds_r <= e.rr_a;
+  g.tight = tuned ? 1 : 0;
+  g.keep_w = tuned ? e.kw_a : e.kw_b;
+  if (!tuned && (kw_need > e.kw_b || g.rounds_r > e.rr_b)) return false;
+  g.nv = (e.spl_w * g.keep_w * 2 + 3) / 4 * 4;
+  g.spec_per_chan = e.spec_per_chan;
+  g.inv_per_chan = g.rounds_r * g.nv * e.nt;
   if (g.ih * g.iw > kMaxPixPerThread * kThreads || g.th * g.tw > kMaxPixPerThread * kThreads) return false;
   if (e.prep_lds_total(g, true) > static_cast<size_t>(kLdsLimit)) return false;
   if (e.prep_lds_total(g, false) > static_cast<size_t>(kLdsLimit)) return false;
@@ -574,7 +611,7 @@ bool fill_geometry(NccGeom& g, const FftEntry& e) {
 
 }  // namespace
 
-bool fft_geometry(NccGeom& g) {
+bool fft_geometry(NccGeom& g, bool pow2_only) {
   const int need_h = fft_need(g.ih, g.th), need_w = fft_need(g.iw, g.tw);
   // the template must also fit the grid (it always does when the image does not alias, except
   // for templates larger than the image)
@@ -583,6 +620,7 @@ bool fft_geometry(NccGeom& g) {
   NccGeom best_g = g;
   for (const FftEntry& e : kEntries) {
     if (e.nh < min_h || e.nw < min_w) continue;
+    if (pow2_only && !e.pow2) continue;
     if (best && static_cast<long long>(e.nh) * e.nw >= static_cast<long long>(best->nh) * best->nw) continue;
     NccGeom trial = g;
     if (!fill_geometry(trial, e)) continue;

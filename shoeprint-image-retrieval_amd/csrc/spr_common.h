@@ -42,11 +42,11 @@ struct NccGeom {
   int eh, tgh, ew, tgw;
   int tight;           // 1: ih <= nh/2 and iw <= nw/2 (the pruned kernel variant), 0: general variant
   int rounds_c;        // column-pass rounds of (kThreads/tgh) columns covering nw/2 columns
-  int sh;              // kept outputs per column sub-transform: rows 0 .. eh*sh-1 cover ih
-  int r_rows;          // eh*sh rows of the intermediate LDS image
+  int r_rows;          // rows of the intermediate LDS image kept after the column pass (ih rounded up to 8)
   int r_stride;        // row stride (complex elements) of the transposed LDS image RT[column][row]
   int rounds_r;        // row-pass rounds of (kThreads/tgw) row pairs covering r_rows/2 pairs (r_rows is even)
   int keep_w;          // kept outputs per row sub-transform (covers iw)
+  int nv;              // 1/sigma values (= accumulators) per lane and row round, a multiple of 4
   int spec_per_chan;   // complex elements of one channel's spectrum (tiled layout)
   int inv_per_chan;    // floats of one channel's 1/sigma map in pair-kernel register order
   // direct method only ---------------------------------------------------------------------
@@ -69,7 +69,7 @@ int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n
 int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
                     hipStream_t stream);
-bool fft_geometry(NccGeom& g);     // fills the FFT fields; false if no instantiated kernel fits
+bool fft_geometry(NccGeom& g, bool pow2_only);  // fills the FFT fields; false if no instantiated kernel fits
 bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps do not fit LDS
 
 // Prepared-buffer sizes (bytes per item), both 256-byte multiples.

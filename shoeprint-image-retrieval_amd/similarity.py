@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import NCC_AUTO, NCC_DIRECT, NCC_FFT, NccShape
 
 CROP = 2  # similarity.py:92-93
-_METHODS = {"auto": NCC_AUTO, "fft": NCC_FFT, "direct": NCC_DIRECT}
+_METHODS = {"auto": NCC_AUTO, "fft": NCC_FFT, "direct": NCC_DIRECT, "fft_pow2": _lib.NCC_FFT_POW2}
 _DTYPES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float16): _lib.F16}
 
 

@@ -42,9 +42,10 @@ def test_emu_shape_classes(scorer, case):
     pc.check_shape_case(scorer, case)
 
 
+@pytest.mark.parametrize("method", ["fft", "fft_pow2"])
 @pytest.mark.parametrize("case", pc.BIG_SHAPE_CASES)
-def test_emu_conv3_sized_maps_fft(case):
-    pc.check_shape_case(emu_scorer("fft"), case)
+def test_emu_conv3_sized_maps_fft(case, method):
+    pc.check_shape_case(emu_scorer(method), case)
 
 
 def test_emu_rank_kernel(scorer):
@@ -81,7 +82,8 @@ def test_emu_auto_method_and_errors():
     sc = emu_scorer("auto")
     assert sc.plan(4, (16, 12), (16, 12)).method == _lib.NCC_FFT
     assert sc.plan(4, (16, 12), (16, 12)).fft_size == (32, 16)
-    assert sc.plan(256, (128, 64), (128, 64)).fft_size == (256, 128)  # VGG16 conv3_3 of a 512x256 print
+    assert sc.plan(256, (128, 64), (128, 64)).fft_size == (192, 96)   # VGG16 conv3_3 of a 512x256 print: 3*2^k grid
+    assert emu_scorer("fft_pow2").plan(256, (128, 64), (128, 64)).fft_size == (256, 128)
     assert sc.plan(512, (64, 32), (64, 32)).fft_size == (128, 64)     # conv4_3
     assert sc.plan(512, (32, 16), (32, 16)).fft_size == (64, 32)      # conv5_3
     with pytest.raises(_lib.SprError) as e:

@@ -19,7 +19,7 @@ def lib():
     return _lib.load_library()  # raises if the in-tree .so is missing: no fallback
 
 
-@pytest.fixture(scope="module", params=["fft", "direct"])
+@pytest.fixture(scope="module", params=["fft", "fft_pow2", "direct"])
 def scorer(request, lib):
     from shoeprint_image_retrieval_amd.similarity import NccScorer
 
