@@ -41,31 +41,47 @@ __device__ __forceinline__ float template_scale(const float* x0, int n, double* 
 }
 
 // Summed-area table of x0 (or of fl32(x0^2)) in float64: sat[(y)*(w+1) + x] = sum of rows < y, cols < x.
-__device__ __forceinline__ void build_sat(const float* x0, int h, int w, double* sat, bool squared) {
+// One lane per row, then one lane per column; the serial scans run in register batches of 8 so that the
+// LDS round trip is paid once per batch and only the float64 adds form the dependent chain.
+__device__ __forceinline__ void build_sat(const float* __restrict__ x0, int h, int w, double* __restrict__ sat,
+                                          bool squared) {
   const int tid = static_cast<int>(threadIdx.x);
   const int stride = w + 1;
+  constexpr int B = 8;
   for (int x = tid; x <= w; x += kThreads) sat[x] = 0.0;
   for (int y = tid; y < h; y += kThreads) {
     double run = 0.0;
     double* row = sat + static_cast<size_t>(y + 1) * stride;
+    const float* src = x0 + y * w;
     row[0] = 0.0;
-    for (int x = 0; x < w; ++x) {
-      const float v = x0[y * w + x];
-      if (squared) {
-        const float sq = v * v;
-        run += static_cast<double>(sq);
-      } else {
-        run += static_cast<double>(v);
+    for (int xb = 0; xb < w; xb += B) {
+      float v[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) v[k] = xb + k < w ? src[xb + k] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        if (squared) {
+          const float sq = v[k] * v[k];
+          run += static_cast<double>(sq);
+        } else {
+          run += static_cast<double>(v[k]);
+        }
+        if (xb + k < w) row[xb + k + 1] = run;
       }
-      row[x + 1] = run;
     }
   }
   __syncthreads();
   for (int x = tid; x <= w; x += kThreads) {
     double run = 0.0;
-    for (int y = 1; y <= h; ++y) {
-      run += sat[static_cast<size_t>(y) * stride + x];
-      sat[static_cast<size_t>(y) * stride + x] = run;
+    for (int yb = 1; yb <= h; yb += B) {
+      double v[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) v[k] = yb + k <= h ? sat[static_cast<size_t>(yb + k) * stride + x] : 0.0;
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        run += v[k];
+        if (yb + k <= h) sat[static_cast<size_t>(yb + k) * stride + x] = run;
+      }
     }
   }
   __syncthreads();

@@ -35,7 +35,9 @@ def build(sanitize: bool | None = None, verbose: bool = False) -> str:
     flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-I", HERE, "-I", CSRC, "-Wall",
              "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable"]
     if sanitize:
-        flags += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-O1"]
+        # trap mode: no sanitizer runtime has to be linked into (or preloaded for) the shared object; any
+        # undefined behaviour executes a trap instruction and kills the test process
+        flags += ["-fsanitize=undefined", "-fsanitize-trap=undefined", "-O1"]
     objs = []
     procs = []
     for s in srcs:
@@ -55,7 +57,7 @@ def build(sanitize: bool | None = None, verbose: bool = False) -> str:
             print(log)
     if failed:
         raise RuntimeError("emulation build failed")
-    link = [CLANG, "-shared", "-pthread", *(["-fsanitize=undefined"] if sanitize else []), *objs, "-o", out]
+    link = [CLANG, "-shared", "-pthread", *objs, "-o", out]
     subprocess.run(link, check=True)
     return out
 

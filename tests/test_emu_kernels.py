@@ -151,3 +151,37 @@ def test_product_refuses_to_run_without_gpu_or_library(tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             TorchDevice()
+
+
+def test_emu_kernels_under_ubsan():
+    """Sanitizer pass on the CPU build (GPU sanitizers are not available on the pool): the UBSan-instrumented
+    (trap mode) emulation library runs a scorer + ranker + variants + extractor slice; any undefined
+    behaviour (misaligned or out-of-bounds-typed access, signed overflow, bad shift ...) kills the process."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import build_emu
+from host_device import HostDevice
+from shoeprint_image_retrieval_amd import _lib, synth, network
+from shoeprint_image_retrieval_amd.similarity import NccScorer, compare_maps
+lib = _lib.load_library(build_emu.build(sanitize=True))
+cfg = {"comparison": {"n_processes": 1, "rotations": [7], "scales": [1.1]},
+       "model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}
+for method in ("fft", "direct"):
+    sc = NccScorer(device=HostDevice(), library=lib, method=method)
+    q, g, m = synth.dataset(3, 2, 5, 3, 20, 14, signal=1, noise=6)
+    print(method, compare_maps(q, g, m, cfg, scorer=sc))
+sc = NccScorer(device=HostDevice(), library=lib, method="fft")
+q, g, m = synth.dataset(4, 1, 2, 2, 128, 64)
+print("conv3 grid", sc.plan(2, (128, 64), (128, 64)).fft_size, sc.score_matrix(q, g))
+mdl = network.Model(cfg, 5, device=HostDevice(), library=lib)
+print(mdl.get_feature_maps(synth.shoeprint_image(1, 0, 24, 20)).shape)
+print("UBSAN-CLEAN")
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu"))
+    env = dict(os.environ, SPR_EMU_THREADS="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "UBSAN-CLEAN" in out.stdout
