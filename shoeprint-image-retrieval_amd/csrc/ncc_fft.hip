@@ -562,6 +562,8 @@ constexpr FftEntry entry() {
 }
 
 // (E, TG) factorisations: 256 = 16*16, 192 = 12*16, 128 = 16*8, 96 = 12*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
+// (96 x 48 and 48 x 24 for the conv4_3 / conv5_3 maps were measured SLOWER than 128 x 64 / 64 x 32: their
+// 8- and 4-lane groups fill only 50-75 % of the 256 lanes and per-channel fixed costs dominate there.)
 //                 EH TGH EW TGW  NT KWA RRA      prefetch buffers of the tuned variant
 const FftEntry kEntries[] = {
     entry<Cfg<8, 4, 4, 4, 256, 2, 1>, 1>(),       // 32 x 16

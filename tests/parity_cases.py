@@ -90,6 +90,7 @@ def check_golden_get_similarity(scorer, max_elems):
 SHAPE_CASES = [  # (C, qh, qw, gh, gw): tight / general variants, odd sizes, template != image size
     (3, 32, 16, 32, 16), (2, 40, 40, 40, 40), (2, 30, 17, 33, 15), (2, 16, 31, 17, 30),
     (2, 20, 20, 50, 40), (2, 50, 40, 20, 20), (1, 13, 9, 20, 16), (2, 64, 32, 64, 32),
+    (3, 60, 30, 64, 32), (2, 32, 16, 30, 18), (2, 44, 22, 44, 22),
 ]
 BIG_SHAPE_CASES = [(3, 128, 64, 128, 64), (2, 100, 70, 100, 70), (2, 90, 50, 120, 70), (2, 126, 62, 128, 64),
                    (2, 128, 64, 130, 60), (2, 97, 41, 110, 52)]
