@@ -223,16 +223,31 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
 // ============================================================================================
 constexpr int kTileQ = 16, kTileG = 16;
 
-template <class C, int RR, int KW, int PF>
+// What the pair kernel needs of the plan, kept small: kernel arguments live in SGPRs, and the packed-math
+// twiddle constants want those too.
+struct PairArgs {
+  int channels, nq, ng;
+  int ih, iw;        // cropped search-map size (debug map output only)
+  int r_rows;        // rows of the intermediate image that matter (pairs = r_rows / 2)
+  int r_stride;      // row stride of the transposed image
+  int rounds_r;      // row rounds actually needed (<= RR)
+  int inv_per_chan;  // floats of 1/sigma per channel
+  int accumulate;
+};
+
+// RK = rows of a column transform's output kept in the LDS image (compile-time for the tuned variant: the
+// stage-2 outputs beyond it are dead code and the stores need no per-row test; 0 = runtime r_rows)
+template <class C, int RR, int KW, int PF, int RK>
 __global__ void __launch_bounds__(C::NT, 2)
-pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
-                const unsigned char* __restrict__ pg, size_t g_item_bytes, int nq, int ng, float* __restrict__ scores,
-                long long ld, long long col0, int accumulate, float* __restrict__ maps_out,
+pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
+                const unsigned char* __restrict__ pg, size_t g_item_bytes, float* __restrict__ scores,
+                long long ld, long long col0, float* __restrict__ maps_out,
                 const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off,
                 unsigned nyq_off_lds) {
   using GH = typename C::GH;
   using GW = typename C::GW;
   // ---- which pair ------------------------------------------------------------------------------
+  const int nq = g.nq, ng = g.ng;
   const int tiles_g = ceil_div(ng, kTileG);
   const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
   const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
@@ -276,8 +291,11 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
     for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
   const int pairs = g.r_rows / 2;
   const int rs = g.r_stride;                    // row stride of the transposed image RT[j][n1]
-  const int s_full = g.r_rows / C::EH;          // column outputs p + EH*s with s < s_full are rows < r_rows ...
-  const int p_part = g.r_rows - s_full * C::EH;  // ... for every p; at s == s_full only p < p_part
+  // column outputs p + EH*s with s < s_full are rows < (RK or, for RK == 0, the runtime r_rows) for every p;
+  // at s == s_full only p < p_part.  Compile-time for the tuned variant.
+  const int rk = RK > 0 ? RK : g.r_rows;
+  const int s_full = rk / C::EH;
+  const int p_part = rk - s_full * C::EH;
 
   // ---- prefetch state --------------------------------------------------------------------------
   float4 nxt[PF][2 * H2];  // H2 x (2 complex of G), H2 x (2 complex of Q) per buffer
@@ -378,8 +396,10 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
           cf* col = R + j * rs + p;
 #pragma unroll
           for (int s = 0; s < C::TGH; ++s) {
-            if (s < s_full) col[C::EH * s] = y[pp][s];                       // uniform
-            else if (s == s_full && p < p_part) col[C::EH * s] = y[pp][s];   // last, partial row block
+            if (s < s_full) col[C::EH * s] = y[pp][s];                      // compile-time
+            else if (s == s_full && p_part > 0) {
+              if (p < p_part) col[C::EH * s] = y[pp][s];                    // last, partial row block
+            }
           }
         }
       }
@@ -452,7 +472,7 @@ pair_fft_kernel(NccGeom g, const unsigned char* __restrict__ pq, size_t q_item_b
   if (tid == 0 && scores) {
     const float s = best / static_cast<float>(g.channels);
     float* dst = scores + static_cast<size_t>(qi) * ld + col0 + gi_item;
-    const float prev = accumulate ? *dst : 0.0f;
+    const float prev = g.accumulate ? *dst : 0.0f;
     *dst = s > prev ? s : prev;
   }
 }
@@ -483,6 +503,10 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
 struct PairFftLds {
   size_t r_off, xbuf_off, nyq_off, total;
 };
+// rows kept by the column pass: the tuned variant covers RR_A row rounds, the general one the whole grid
+template <class C>
+constexpr int rk_tuned() { return C::RR_A * C::PPR * 2 < C::NH ? C::RR_A * C::PPR * 2 : C::NH; }
+
 template <class C>
 PairFftLds pair_fft_lds(const NccGeom& g) {
   PairFftLds l;
@@ -496,7 +520,7 @@ PairFftLds pair_fft_lds(const NccGeom& g) {
 // One entry per instantiated (nh, nw) grid.
 struct FftEntry {
   int nh, nw, eh, tgh, ew, tgw, nt, spl_w;
-  int kw_a, rr_a, kw_b, rr_b;
+  int kw_a, rr_a, kw_b, rr_b, rk_a;
   bool pow2;
   int spec_per_chan;
   size_t (*prep_lds_total)(const NccGeom&, bool);
@@ -525,18 +549,22 @@ int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* p
   return check_launch("prep_fft_kernel");
 }
 
-template <class C, int RR, int KW, int PF>
+template <class C, int RR, int KW, int PF, int RK>
 int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
                 int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, hipStream_t stream) {
   const PairFftLds l = pair_fft_lds<C>(g);
   const int64_t tiles = static_cast<int64_t>(ceil_div(static_cast<int>(nq), kTileQ)) * ceil_div(static_cast<int>(ng), kTileG);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF>),
+  PairArgs a{};
+  a.channels = g.channels; a.nq = static_cast<int>(nq); a.ng = static_cast<int>(ng);
+  a.ih = g.ih; a.iw = g.iw; a.r_rows = g.r_rows; a.r_stride = g.r_stride; a.rounds_r = g.rounds_r;
+  a.inv_per_chan = g.inv_per_chan; a.accumulate = accumulate;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
-                     dim3(C::NT), l.total, stream, g, static_cast<const unsigned char*>(pq),
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
+                     dim3(C::NT), l.total, stream, a, static_cast<const unsigned char*>(pq),
                      prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
-                     prepared_gallery_item_bytes(g, SPR_NCC_FFT), static_cast<int>(nq), static_cast<int>(ng), scores,
-                     static_cast<long long>(ld), static_cast<long long>(col0), accumulate, maps_out, tw_h, tw_w,
+                     prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores,
+                     static_cast<long long>(ld), static_cast<long long>(col0), maps_out, tw_h, tw_w,
                      static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off),
                      static_cast<unsigned>(l.nyq_off));
   return check_launch("pair_fft_kernel");
@@ -548,16 +576,17 @@ int pair_t(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void*
            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
            hipStream_t stream) {
   if (tuned)
-    return pair_launch<C, C::RR_A, C::KW_A, PFA>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
-                                                 stream);
-  return pair_launch<C, C::RR_B, C::KW_B, 1>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
-                                             stream);
+    return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>()>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out,
+                                                                tw_h, tw_w, stream);
+  return pair_launch<C, C::RR_B, C::KW_B, 1, 0>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                                stream);
 }
 
 template <class C, int PFA>
 constexpr FftEntry entry() {
   return FftEntry{C::NH,   C::NW,   C::EH,   C::TGH,  C::EW,   C::TGW, C::NT, C::GW::SPL,
-                  C::KW_A, C::RR_A, C::KW_B, C::RR_B, (C::NH & (C::NH - 1)) == 0 && (C::NW & (C::NW - 1)) == 0,
+                  C::KW_A, C::RR_A, C::KW_B, C::RR_B, rk_tuned<C>(),
+                  (C::NH & (C::NH - 1)) == 0 && (C::NW & (C::NW - 1)) == 0,
                   C::kSpecPerChan, prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C, PFA>};
 }
 
@@ -594,10 +623,10 @@ bool fill_geometry(NccGeom& g, const FftEntry& e) {
   g.rounds_c = ceil_div(e.nw / 2, cpr);
   g.r_rows = (g.ih + 7) / 8 * 8;  // rows kept after the column pass (even; rows >= ih carry 1/sigma = 0)
   if (g.r_rows > e.nh) g.r_rows = e.nh;
-  g.r_stride = rt_stride(g.r_rows);
   g.rounds_r = ceil_div(g.r_rows / 2, ppr);
   const int kw_need = ceil_div(g.iw, e.ew);  // row outputs n2 = p + ew*s with s < kw_need cover iw
   const bool tuned = kw_need <= e.kw_a && g.rounds_r <= e.rr_a;
+  g.r_stride = rt_stride(tuned ? e.rk_a : g.r_rows);  // the image holds every row the variant's column pass keeps
   g.tight = tuned ? 1 : 0;
   g.keep_w = tuned ? e.kw_a : e.kw_b;
   if (!tuned && (kw_need > e.kw_b || g.rounds_r > e.rr_b)) return false;
