@@ -223,10 +223,6 @@ __device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, c
   using G = GroupFft<E, TG>;
   static_assert(SPL == G::SPL, "y must be [GroupFft<E,TG>::SPL][TG]");
   Dft<E, DIR>::run(x);
-  if constexpr (E < TG) {
-#pragma unroll
-    for (int tt = 0; tt < TG; ++tt) y[0][tt] = cmake(0.0f, 0.0f);  // lanes t >= E own no sub-transform
-  }
 #pragma unroll
   for (int ph = 0; ph < G::NPH; ++ph) {
 #pragma unroll
@@ -236,15 +232,26 @@ __device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, c
     }
     wave_sync();
     constexpr int kE = E, kTG = TG;
-    const int pp = kE >= kTG ? ph : 0;        // the sub-transform set this phase feeds
+    const int kValid = kE - G::PH * ph < G::PH ? kE - G::PH * ph : G::PH;  // image rows this phase wrote (folds after unrolling)
+    const int pp = kE >= kTG ? ph : 0;         // the sub-transform set this phase feeds
     const int row = t + TG * pp - G::PH * ph;  // image row holding this lane's p = t + TG*pp, if in this phase
-    const bool have = (E % TG == 0) || (row >= 0 && row < G::PH && t + TG * pp < E);
-    if (have) {
+    if constexpr (E % TG == 0) {
 #pragma unroll
       for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[row * G::kRow + tt];
-    } else if (kE >= kTG) {
+    } else {
+      // Lanes that own no sub-transform in this set (p >= E) still need defined, finite inputs: they read some
+      // valid row — their results are never stored (column pass) or meet a zero 1/sigma (row pass) — which
+      // avoids zero-filling registers and an exec-masked branch.  When E < TG spans several phases, a later
+      // phase may only overwrite the lanes whose row it carries.
+      const bool own = row >= 0 && row < kValid;
+      const int rsafe = own ? row : (t % kValid);
+      if (kE >= kTG || ph == 0) {
 #pragma unroll
-      for (int tt = 0; tt < TG; ++tt) y[pp][tt] = cmake(0.0f, 0.0f);
+        for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[rsafe * G::kRow + tt];
+      } else if (own) {
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) y[pp][tt] = xbuf[row * G::kRow + tt];
+      }
     }
     wave_sync();  // the image is rewritten by the next phase / the next call
     if constexpr (E >= TG) Dft<TG, DIR>::run(y[ph]);

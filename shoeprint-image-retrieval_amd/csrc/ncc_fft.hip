@@ -442,17 +442,24 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
       for (int pp = 0; pp < GW::SPL; ++pp) {
 #pragma unroll
         for (int s = 0; s < KW; ++s) {
-          const cf v = y[pp][s];  // lanes without a sub-transform pp hold zeros and their 1/sigma slots are 0
+          const cf v = y[pp][s];  // lanes without a sub-transform pp hold finite junk and their 1/sigma slots are 0
           const int e = (pp * KW + s) * 2;
-          const float va = v.x * ivf[e], vb = v.y * ivf[e + 1];
-          acc[rr][e] += va;
-          acc[rr][e + 1] += vb;
-          if (maps_out) {
+          acc[rr][e] = fmaf(v.x, ivf[e], acc[rr][e]);
+          acc[rr][e + 1] = fmaf(v.y, ivf[e + 1], acc[rr][e + 1]);
+        }
+      }
+      if (maps_out) {  // debug / parity output of the per-channel maps (spr_ncc_maps): one uniform branch
+#pragma unroll
+        for (int pp = 0; pp < GW::SPL; ++pp) {
+#pragma unroll
+          for (int s = 0; s < KW; ++s) {
+            const cf v = y[pp][s];
+            const int e = (pp * KW + s) * 2;
             const int n2 = GW::out_index(tr, pp, s);
             const int n1 = 2 * (rr * C::PPR + gr);
             const bool ok = GW::out_valid(tr, pp) && n2 < g.iw;
-            if (ok && n1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1) * g.iw + n2] = va;
-            if (ok && n1 + 1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1 + 1) * g.iw + n2] = vb;
+            if (ok && n1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1) * g.iw + n2] = v.x * ivf[e];
+            if (ok && n1 + 1 < g.ih) maps_out[(static_cast<size_t>(c) * g.ih + n1 + 1) * g.iw + n2] = v.y * ivf[e + 1];
           }
         }
       }
