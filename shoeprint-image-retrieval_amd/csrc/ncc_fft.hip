@@ -218,8 +218,11 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
 //   * no wait is placed by hand: loads are issued early and the compiler's counted s_waitcnt sits at
 //     the first use.
 // Pair -> workgroup mapping: 1-D grid in tiles of 16 queries x 16 gallery items.  Workgroups are dealt
-// round-robin over the 8 XCDs, so workgroup w of a tile (w % 8 = XCD group) takes a 4-query x 8-gallery
-// sub-tile: the 32 workgroups sharing one L2 touch only 4 + 8 distinct spectra per channel.
+// round-robin over the 8 XCDs, so workgroup w of a tile (w % 8 = XCD group) takes a 16-query x 2-gallery
+// sub-tile: a gallery item's spectrum + 1/sigma slice (116 KB per channel, the larger side) then has 16
+// readers on the same L2 and a query spectrum (75 KB) 2 (4 with the co-resident next tile).  Measured at
+// Q=100 x G=1500: 228 k pairs/s against 173 k with 4-query x 8-gallery sub-tiles — workgroups drift apart
+// by a channel or more, and the more readers a line has the likelier one of them is still close in time.
 // ============================================================================================
 constexpr int kTileQ = 16, kTileG = 16;
 
@@ -253,8 +256,8 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
   const int tq = tile / tiles_g, tg = tile - tq * tiles_g;
   const int xcd = within & 7, slot = within >> 3;  // 8 XCD groups x 32 slots
-  const int qi = tq * kTileQ + 4 * (xcd >> 1) + (slot >> 3);
-  const int gi_item = tg * kTileG + 8 * (xcd & 1) + (slot & 7);
+  const int qi = tq * kTileQ + (slot >> 1);
+  const int gi_item = tg * kTileG + 2 * xcd + (slot & 1);
   if (qi >= nq || gi_item >= ng) return;  // uniform per workgroup
 
   unsigned char* lds = dyn_lds();
