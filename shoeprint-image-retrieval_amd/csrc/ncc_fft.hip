@@ -74,7 +74,7 @@ template <class C>
 __global__ void __launch_bounds__(kThreads)
 prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                 size_t item_bytes, const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned x0_off,
-                unsigned f_off, unsigned xbuf_off, unsigned zbuf_off, int f_stride) {
+                unsigned f_off, unsigned xbuf_off, unsigned zbuf_off, unsigned sat2_off, int f_stride) {
   using GH = typename C::GH;
   using GW = typename C::GW;
   unsigned char* lds = dyn_lds();
@@ -102,11 +102,9 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     // 1/sigma map in the pair kernel's register order; slots no pixel maps to stay 0.
     float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
                  static_cast<size_t>(c) * g.inv_per_chan;
-    for (int i = tid; i < g.inv_per_chan; i += kThreads) inv[i] = 0.0f;
-    __syncthreads();
+    // (the slots no pixel maps to were zeroed by a stream memset ahead of this launch)
     const int nv = g.nv;
-    inv_sigma_map(x0, h, w, g.th, g.tw, sat, [&](int i, float v) {
-      const int n1 = i / w, n2 = i - n1 * w;
+    auto store = [&](int n1, int n2, float v) {
       const int pr = n1 >> 1, ab = n1 & 1;
       const int rr = pr / C::PPR, giw = pr - rr * C::PPR;
       const int p = n2 % C::EW, s = n2 / C::EW;       // output n2 = p + EW*s of the row transform
@@ -114,7 +112,12 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
       const int e2 = (pp * g.keep_w + s) * 2 + ab;
       const int lane = giw * C::TGW + t;
       inv[((rr * (nv / 4) + (e2 >> 2)) * C::NT + lane) * 4 + (e2 & 3)] = v;
-    });
+    };
+    if (sat2_off != 0) {
+      inv_sigma_map_fused(x0, h, w, g.th, g.tw, sat, reinterpret_cast<double*>(lds + sat2_off), store);
+    } else {
+      inv_sigma_map(x0, h, w, g.th, g.tw, sat, [&](int i, float v) { store(i / w, i % w, v); });
+    }
   }
 
   // ---- row pass: two real rows per complex transform of length NW -------------------------------
@@ -491,7 +494,7 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
 // Host side: configurations, LDS layouts, dispatch
 // ============================================================================================
 struct PrepFftLds {
-  size_t x0_off, f_off, xbuf_off, zbuf_off, total;
+  size_t x0_off, f_off, xbuf_off, zbuf_off, sat2_off, total;  // sat2_off = 0: the two tables do not fit together
   int f_stride;
 };
 template <class C>
@@ -505,7 +508,13 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
   l.xbuf_off = align_up(l.f_off + f_bytes, 16);
   l.zbuf_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads), 16);
   const size_t fft_total = l.zbuf_off + sizeof(cf) * (kThreads / C::TGW) * C::NW;
-  const size_t sat_total = is_query ? 0 : l.f_off + sizeof(double) * (h + 1) * (w + 1);
+  const size_t sat_bytes = align_up(sizeof(double) * (h + 1) * (w + 1), 16);
+  size_t sat_total = is_query ? 0 : l.f_off + sat_bytes;
+  l.sat2_off = 0;
+  if (!is_query && l.f_off + 2 * sat_bytes <= static_cast<size_t>(kLdsLimit)) {  // single-sweep 1/sigma
+    l.sat2_off = l.f_off + sat_bytes;
+    sat_total = l.f_off + 2 * sat_bytes;
+  }
   l.total = fft_total > sat_total ? fft_total : sat_total;
   return l;
 }
@@ -552,10 +561,22 @@ int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* p
   const size_t item_bytes = is_query ? prepared_query_item_bytes(g, SPR_NCC_FFT) : prepared_gallery_item_bytes(g, SPR_NCC_FFT);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kLdsLimit);
+  if (!is_query) {
+    // 1/sigma slots that no pixel maps to (rows >= ih, columns >= iw, surplus lanes) must read as 0
+    // (one strided fill: n rows of the items' 1/sigma part, pitch = item size)
+    const size_t spec_bytes = sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan;
+    if (hipMemset2DAsync(static_cast<unsigned char*>(prepared) + spec_bytes, item_bytes, 0,
+                         sizeof(float) * static_cast<size_t>(g.channels) * g.inv_per_chan, static_cast<size_t>(n),
+                         stream) != hipSuccess) {
+      set_error("hipMemset2DAsync(1/sigma) failed");
+      return SPR_ERR_HIP;
+    }
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads),
                      l.total, stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes, tw_h,
                      tw_w, static_cast<unsigned>(l.x0_off), static_cast<unsigned>(l.f_off),
-                     static_cast<unsigned>(l.xbuf_off), static_cast<unsigned>(l.zbuf_off), l.f_stride);
+                     static_cast<unsigned>(l.xbuf_off), static_cast<unsigned>(l.zbuf_off),
+                     static_cast<unsigned>(l.sat2_off), l.f_stride);
   return check_launch("prep_fft_kernel");
 }
 

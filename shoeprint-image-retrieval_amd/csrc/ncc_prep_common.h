@@ -15,11 +15,15 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
   const int tid = static_cast<int>(threadIdx.x);
   const int n = h * w;
   double s = 0.0;
+  // (y, x) of pixel i = tid + k*kThreads advance incrementally: one division per lane, not per pixel
+  const int dy = kThreads / w, dx = kThreads - dy * w;
+  int y = tid / w, x = tid - y * w;
   for (int i = tid; i < n; i += kThreads) {
-    const int y = i / w, x = i - y * w;
     const float v = load_feature(maps, chan_base + static_cast<size_t>(y + crop) * raw_w + (x + crop), dtype);
     x0[i] = v;
     s += static_cast<double>(v);
+    x += dx; y += dy;
+    if (x >= w) { x -= w; ++y; }
   }
   const double total = block_sum(s, red);
   const float mean = static_cast<float>(total / static_cast<double>(n));
@@ -100,6 +104,92 @@ __device__ __forceinline__ double window_sum(const double* sat, int h, int w, in
          sat[static_cast<size_t>(y1) * stride + x0] + sat[static_cast<size_t>(y0) * stride + x0];
 }
 
+// Both tables in one sweep (two running sums per scan): sat1 of x0, sat2 of fl32(x0^2).
+__device__ __forceinline__ void build_sat_pair(const float* __restrict__ x0, int h, int w, double* __restrict__ sat1,
+                                               double* __restrict__ sat2) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int stride = w + 1;
+  constexpr int B = 8;
+  for (int x = tid; x <= w; x += kThreads) { sat1[x] = 0.0; sat2[x] = 0.0; }
+  for (int y = tid; y < h; y += kThreads) {
+    double r1 = 0.0, r2 = 0.0;
+    double* row1 = sat1 + static_cast<size_t>(y + 1) * stride;
+    double* row2 = sat2 + static_cast<size_t>(y + 1) * stride;
+    const float* src = x0 + y * w;
+    row1[0] = 0.0; row2[0] = 0.0;
+    for (int xb = 0; xb < w; xb += B) {
+      float v[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) v[k] = xb + k < w ? src[xb + k] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const float sq = v[k] * v[k];  // np.square keeps float32 (similarity.py:57)
+        r1 += static_cast<double>(v[k]);
+        r2 += static_cast<double>(sq);
+        if (xb + k < w) { row1[xb + k + 1] = r1; row2[xb + k + 1] = r2; }
+      }
+    }
+  }
+  __syncthreads();
+  // column scans: lanes [0, w] take table 1, lanes [w+1, 2w+1] table 2
+  for (int j = tid; j < 2 * stride; j += kThreads) {
+    double* sat = j < stride ? sat1 : sat2;
+    const int x = j < stride ? j : j - stride;
+    double run = 0.0;
+    for (int yb = 1; yb <= h; yb += B) {
+      double v[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) v[k] = yb + k <= h ? sat[static_cast<size_t>(yb + k) * stride + x] : 0.0;
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        run += v[k];
+        if (yb + k <= h) sat[static_cast<size_t>(yb + k) * stride + x] = run;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// 1/sigma from the two window sums: var = S2 - S1^2/(th*tw) in float64 (that is where the cancellation is),
+// var <= 0 -> 0 (similarity.py:65, :70); the reciprocal square root of the positive result only needs float32
+// accuracy (hardware v_rsq_f32, ~1 ulp: relative error ~2e-7).
+__device__ __forceinline__ float inv_sigma_from_sums(double s1, double s2, double inv_n) {
+  const double var = s2 - s1 * s1 * inv_n;
+  float inv = 0.0f;
+  if (var > 0.0) {
+    inv = rsqrtf(static_cast<float>(var));
+    if (!(inv <= 3.0e38f)) inv = 0.0f;  // variance below the float32 range: treat as non-finite -> 0
+  }
+  return inv;
+}
+
+// Single-sweep form of inv_sigma_map for maps whose two tables fit LDS together (2*(h+1)*(w+1) doubles).
+// `store(y, x, value)`.
+template <class Store>
+__device__ __forceinline__ void inv_sigma_map_fused(const float* x0, int h, int w, int th, int tw, double* sat1,
+                                                    double* sat2, Store store) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int n = h * w;
+  build_sat_pair(x0, h, w, sat1, sat2);
+  const double inv_n = 1.0 / (static_cast<double>(th) * static_cast<double>(tw));
+  const int stride = w + 1;
+  const int dy = kThreads / w, dx = kThreads - dy * w;
+  int y = tid / w, x = tid - y * w;
+  for (int i = tid; i < n; i += kThreads) {
+    int y0 = y - th / 2, y1 = y0 + th, xa = x - tw / 2, xb = xa + tw;
+    y0 = y0 < 0 ? 0 : y0;  y1 = y1 > h ? h : y1;  // (y0 <= h and y1 >= 0 always: 0 <= y < h, th >= 1)
+    xa = xa < 0 ? 0 : xa;  xb = xb > w ? w : xb;
+    y0 = y0 > h ? h : y0;  xa = xa > w ? w : xa;  y1 = y1 < 0 ? 0 : y1;  xb = xb < 0 ? 0 : xb;
+    const int i11 = y1 * stride + xb, i01 = y0 * stride + xb, i10 = y1 * stride + xa, i00 = y0 * stride + xa;
+    const double s1 = sat1[i11] - sat1[i01] - sat1[i10] + sat1[i00];
+    const double s2 = sat2[i11] - sat2[i01] - sat2[i10] + sat2[i00];
+    store(y, x, inv_sigma_from_sums(s1, s2, inv_n));
+    x += dx; y += dy;
+    if (x >= w) { x -= w; ++y; }
+  }
+  __syncthreads();
+}
+
 // inv_sigma for every pixel of the centred map x0 (h x w), for a th x tw template:
 // var = S2 - S1^2/(th*tw) in float64, var <= 0 -> 0 (the reference clamps negatives to 0 and
 // turns the resulting division by zero into 0, :65, :70).  `store(i, value)` receives pixel
@@ -128,13 +218,7 @@ __device__ __forceinline__ void inv_sigma_map(const float* x0, int h, int w, int
     if (i < n) {
       const int y = i / w, x = i - y * w;
       const double s2 = window_sum(sat, h, w, th, tw, y, x);
-      const double var = s2 - s1[k] * s1[k] * inv_n;
-      float inv = 0.0f;
-      if (var > 0.0) {
-        inv = static_cast<float>(1.0 / sqrt(var));
-        if (!(inv <= 3.0e38f)) inv = 0.0f;  // overflow of a denormal variance: treat as non-finite -> 0
-      }
-      store(i, inv);
+      store(i, inv_sigma_from_sums(s1[k], s2, inv_n));
     }
   }
   __syncthreads();
