@@ -359,7 +359,14 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     const int tidv = opaque(tid0);
     const int gc = tidv / C::TGH, tc = tidv - gc * C::TGH;  // column-pass group / lane in group
     const int gr = tidv / C::TGW, tr = tidv - gr * C::TGW;  // row-pass group / lane in group
-    const LdsTwiddles<C::TGH> twc{twt_h, tc};
+    // column twiddles: with several column rounds per channel they are read from the LDS table once per
+    // channel into registers (live only across the column pass); the row pass reads its table at use
+    RegTwiddles<C::EH> twc_reg;
+    const LdsTwiddles<C::TGH> twc_lds{twt_h, tc};
+    if constexpr (RC > 1) {
+#pragma unroll
+      for (int p = 0; p < C::EH; ++p) twc_reg.w[p] = twc_lds.get(p);
+    }
     const LdsTwiddles<C::TGW> twr{twt_w, tr};
     cf* cbuf = xbuf + gc * GH::kGroupElems;
     cf* rbuf = xbuf + gr * GW::kGroupElems;
@@ -393,7 +400,8 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
           z[m] = pk_add_i(z[m], cmul(nyq[k1], nyq[C::NH + k1]));
         }
       }
-      group_fft<C::EH, C::TGH, +1>(z, y, tc, twc, cbuf);
+      if constexpr (RC > 1) group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_reg, cbuf);
+      else group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_lds, cbuf);
       if (active) {
 #pragma unroll
         for (int pp = 0; pp < GH::SPL; ++pp) {
@@ -413,6 +421,11 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     __syncthreads();
     issue_inv(c);  // consumed after this channel's row transforms
     issue_nyq(c + 1);
+    RegTwiddles<C::EW> twr_reg;  // row twiddles: same reasoning, live only across the row pass
+    if constexpr (RR > 1) {
+#pragma unroll
+      for (int p = 0; p < C::EW; ++p) twr_reg.w[p] = twr.get(p);
+    }
     // ---- row pass: two real rows per inverse transform along k2 -> * 1/sigma -> accumulate --------
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
@@ -442,7 +455,8 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
           wv[m] = pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // conj(Ya) + i*conj(Yb)
         }
       }
-      group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr, rbuf);
+      if constexpr (RR > 1) group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr_reg, rbuf);
+      else group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr, rbuf);
       const float* ivf = reinterpret_cast<const float*>(inv_nxt[rr]);
 #pragma unroll
       for (int pp = 0; pp < GW::SPL; ++pp) {
