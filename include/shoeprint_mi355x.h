@@ -166,8 +166,15 @@ int spr_resample_axis(const float* in, float* out, int64_t n_maps, int32_t h, in
  * Pre-processing fused into the first layer (network.py:60-71, 127-130): x'_c = (pixel/255 - mean_c)/std_c
  * with the zero padding applied AFTER normalisation.  `mean`/`inv_std` are the three per-channel values in
  * [0,1] units (VGG16: mean (0.48235, 0.45882, 0.40784), std 1/255 each).  CLAHE (network.py:197-208) is
- * applied by the caller before this entry point.
+ * a separate entry point (spr_clahe_u8) the caller runs before this one.
  */
+/* CLAHE of n uint8 images [n, h, w] (device), OpenCV's 8-bit algorithm: tile grid tiles_x x tiles_y
+ * (cv2 tileGridSize = (x, y)), clip limit as in cv2.createCLAHE.  workspace: device buffer of
+ * spr_clahe_workspace_bytes() (the per-tile look-up tables).  in and out may not alias. */
+size_t spr_clahe_workspace_bytes(int64_t n, int32_t tiles_x, int32_t tiles_y);
+int spr_clahe_u8(const uint8_t* in, uint8_t* out, int64_t n, int32_t h, int32_t w, float clip_limit,
+                 int32_t tiles_x, int32_t tiles_y, void* workspace, spr_stream_t stream);
+
 typedef struct spr_vgg16_plan spr_vgg16_plan;
 
 int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out);

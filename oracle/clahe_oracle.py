@@ -1,12 +1,13 @@
-"""CLAHE pre-processing (reference network.py:108-111, 197-208: cv2.createCLAHE(...).apply on uint8).
+"""CPU oracle for CLAHE pre-processing (reference network.py:108-111, 197-208: cv2.createCLAHE(...).apply).
 
+TEST INFRASTRUCTURE ONLY (same rules as ncc_oracle.py): the product runs csrc/clahe.hip.
 The reference runs OpenCV's CLAHE on the CPU, once per image, before the network; OpenCV is not
 installable offline, so this is a numpy restatement of OpenCV's published 8-bit algorithm
 (modules/imgproc/src/clahe.cpp, 4.x): reflect-101 padding to a multiple of the tile grid, per-tile
 256-bin histogram, clip at max(1, int(clipLimit * tileArea / 256)) with uniform redistribution of the
 excess plus the strided residual, cumulative LUT scaled by 255 / tileArea, bilinear interpolation of
 the four neighbouring tile LUTs in float32.  PARITY UNPINNED: no cv2 here and the reference holds no
-CLAHE fixtures; it stays on the host (pre-processing).
+CLAHE fixtures; the HIP kernels are held bit-for-bit to this restatement.
 """
 
 from __future__ import annotations

@@ -28,7 +28,7 @@ from typing import Any
 
 import numpy as np
 
-from . import _lib, clahe as _clahe_mod, synth
+from . import _lib, synth
 
 VGG16_MEAN = (0.48235, 0.45882, 0.40784)                     # network.py:128
 VGG16_STD = (0.00392156862745098,) * 3                       # network.py:129
@@ -138,11 +138,23 @@ class Model:
                                                   dev.ptr(self.packed), dev.ptr(ws), dev.ptr(out), dev.stream()))
         return out
 
+    def clahe_device(self, images_dev):
+        """CLAHE of a uint8 device batch [N,H,W] (network.py:108-111, 206) — HIP kernels, stays in HBM."""
+        dev = self.dev
+        n, h, w = dev.shape(images_dev)
+        tx, ty = int(self.clahe_tile_grid_size[0]), int(self.clahe_tile_grid_size[1])
+        out = dev.empty((n, h, w), np.uint8)
+        ws = dev.empty_bytes(max(16, self.lib.spr_clahe_workspace_bytes(n, tx, ty)))
+        self.lib.check(self.lib.spr_clahe_u8(dev.ptr(images_dev), dev.ptr(out), n, h, w, self.clahe_clip_limit, tx, ty,
+                                             dev.ptr(ws), dev.stream()))
+        return out
+
     def _clahe(self, img: np.ndarray) -> np.ndarray:
         """CLAHE before the network (network.py:197-208); grey images only (the LAB route for RGB is not built)."""
         if img.ndim == 3:
             raise NotImplementedError("CLAHE of RGB images (RGB->LAB->CLAHE(L)->RGB, network.py:199-204) is not built")
-        return _clahe_mod.clahe(img, self.clahe_clip_limit, self.clahe_tile_grid_size)
+        batch = self.dev.to_device(np.ascontiguousarray(img, dtype=np.uint8)[None])
+        return self.dev.to_host(self.clahe_device(batch))[0]
 
     def get_feature_maps(self, img: np.ndarray) -> np.ndarray:
         """One image (uint8 [H,W]) -> float32 [C,h,w], a fresh C-contiguous array (network.py:210-244)."""
@@ -159,8 +171,10 @@ class Model:
         for shape, idx in groups.items():
             for start in range(0, len(idx), self.batch_size):
                 part = idx[start:start + self.batch_size]
-                batch = np.stack([self._clahe(np.ascontiguousarray(images[i], dtype=np.uint8)) for i in part])
-                feats = self.dev.to_host(self.extract_device(self.dev.to_device(batch), in_channels=1))
+                if len(shape) != 2:
+                    raise NotImplementedError("RGB images (network.py:199-204, transform_rgb) are not built: grey [H,W] only")
+                batch = self.dev.to_device(np.stack([np.ascontiguousarray(images[i], dtype=np.uint8) for i in part]))
+                feats = self.dev.to_host(self.extract_device(self.clahe_device(batch), in_channels=1))
                 for k, i in enumerate(part):
                     results[i] = np.ascontiguousarray(feats[k])
                 done += len(part)

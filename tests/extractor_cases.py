@@ -4,7 +4,7 @@ reference, see its header).  Tolerance: 2e-5 of the largest activation (float32 
 
 import numpy as np
 
-from oracle import ncc_oracle, vgg_oracle
+from oracle import clahe_oracle, ncc_oracle, vgg_oracle
 from shoeprint_image_retrieval_amd import network, similarity, synth
 
 CFG = {"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]},
@@ -38,7 +38,7 @@ def check_reference_surface(device, lib):
     assert isinstance(maps, list) and len(maps) == 4
     for im, fm in zip(imgs, maps):
         assert fm.dtype == np.float32 and fm.flags["C_CONTIGUOUS"] and fm.ndim == 3
-        ref = vgg_oracle.get_feature_maps(m._clahe(im), 5, params)
+        ref = vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), 5, params)
         np.testing.assert_allclose(fm, ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
     single = m.get_feature_maps(imgs[1])
     np.testing.assert_array_equal(single, maps[1])
@@ -67,8 +67,8 @@ def check_end_to_end(device, lib, scorer, block=10, hw=(64, 48), n_gallery=6, n_
     gf = m.get_multiple_feature_maps(gallery, progress=False)
     qf = m.get_multiple_feature_maps(queries, progress=False)
     ranks = similarity.compare_maps(qf, gf, matches, CFG, scorer=scorer)
-    ref_gf = [vgg_oracle.get_feature_maps(m._clahe(im), block, params) for im in gallery]
-    ref_qf = [vgg_oracle.get_feature_maps(m._clahe(im), block, params) for im in queries]
+    ref_gf = [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), block, params) for im in gallery]
+    ref_qf = [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), block, params) for im in queries]
     ref_ranks, ref_mat = ncc_oracle.compare_maps(ref_qf, ref_gf, matches, CFG, return_matrix=True)
     mat = scorer.score_matrix(qf, gf)
     np.testing.assert_allclose(mat, ref_mat, atol=1e-4, rtol=0)
