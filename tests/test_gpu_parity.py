@@ -200,3 +200,31 @@ def test_clahe_kernels_match_the_restatement(hw, grid, clip, torch_dev, lib):
     got = torch_dev.to_host(m.clahe_device(torch_dev.to_device(imgs)))
     for i in range(len(imgs)):
         np.testing.assert_array_equal(got[i], clahe_oracle.clahe(imgs[i], clip, grid))
+
+
+# ------------------------------------------------------------------------------ run.toml-driven end to end (f3)
+def test_run_driver_on_an_image_directory(tmp_path, capsys):
+    """run_mi355x.main(run.toml) on a two-cluster Gallery/Query directory == dataloader -> oracle chain."""
+    import dataset_util
+    import run_mi355x
+    from oracle import clahe_oracle, vgg_oracle
+    from shoeprint_image_retrieval_amd import synth
+    from shoeprint_image_retrieval_amd.dataloader import Dataloader
+
+    case = next(c for c in dataset_util.CASES if c["name"] == "wvu_split")
+    cfg = dataset_util.write_dataset(str(tmp_path), case)
+    toml = tmp_path / "run.toml"
+    toml.write_text(
+        f'[dataset]\ndir = "{tmp_path}"\ntype = "WVU2019"\ncrop = {case["crop"]}\nn_processes = 3\nn_clusters = 2\n'
+        f'cluster_minimise_tolerance = 0.05\n[model]\ntype = "VGG16"\nclahe_clip_limit = 2.0\nclahe_tile_grid_size = [8, 8]\n'
+        f'start_block = 16\nend_block = 9\nskip_blocks = []\nminimum_dim = 120\nmaximum_dim = 200\n'
+        f'[comparison]\nn_processes = 2\n')
+    got = run_mi355x.main(str(toml))
+    out = capsys.readouterr().out
+    assert "2 clusters of image sizes found." in out and "rank-1:" in out
+    want = []
+    for queries, gallery, matches, block in Dataloader(cfg):
+        params = synth.vgg16_parameters(1234, vgg_oracle.conv_shapes(block))
+        feats = lambda ims: [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), block, params) for im in ims]
+        want += [int(r) for r in oracle.compare_maps(feats(queries), feats(gallery), matches, cfg)]
+    assert got == want
