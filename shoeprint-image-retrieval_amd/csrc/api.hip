@@ -52,6 +52,7 @@ struct spr_ncc_plan {
   int method;              // resolved: SPR_NCC_FFT or SPR_NCC_DIRECT
   spr::cf* tw_h = nullptr;  // device: exp(-2*pi*i*k/nh), k < nh
   spr::cf* tw_w = nullptr;  // device: exp(-2*pi*i*k/nw), k < nw
+  unsigned* team_sync = nullptr;  // device: arrival counters of the pair kernel's 8 workgroup teams
 };
 
 using namespace spr;
@@ -134,6 +135,10 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   if (method == SPR_NCC_FFT) {
     int rc = make_twiddles(p->geom.nh, &p->tw_h);
     if (rc == SPR_OK) rc = make_twiddles(p->geom.nw, &p->tw_w);
+    if (rc == SPR_OK && hipMalloc(reinterpret_cast<void**>(&p->team_sync), sizeof(unsigned) * 8 * 32) != hipSuccess) {
+      set_error("hipMalloc(team counters) failed");
+      rc = SPR_ERR_HIP;
+    }
     if (rc != SPR_OK) { spr_ncc_plan_destroy(p); return rc; }
   }
   *plan_out = p;
@@ -144,6 +149,7 @@ extern "C" void spr_ncc_plan_destroy(spr_ncc_plan* plan) {
   if (!plan) return;
   if (plan->tw_h) (void)hipFree(plan->tw_h);
   if (plan->tw_w) (void)hipFree(plan->tw_w);
+  if (plan->team_sync) (void)hipFree(plan->team_sync);
   delete plan;
 }
 
@@ -196,7 +202,7 @@ extern "C" int spr_ncc_score(spr_ncc_plan* plan, const void* pq, int64_t nq, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan->method == SPR_NCC_FFT)
     return launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
-                           plan->tw_w, s);
+                           plan->tw_w, plan->team_sync, s);
   return launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
 }
 
@@ -204,6 +210,6 @@ extern "C" int spr_ncc_maps(spr_ncc_plan* plan, const void* pq, const void* pg, 
   if (!plan || !pq || !pg || !maps_out) { set_error("spr_ncc_maps: null pointer"); return SPR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan->method == SPR_NCC_FFT)
-    return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w, s);
+    return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w, nullptr, s);
   return launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
 }

@@ -25,6 +25,8 @@
 // Half-spectrum bookkeeping (rows are real => X[k1][nw-k2] = conj(X[-k1][k2])):
 //   columns k2 = 0 .. nw/2 are stored; the pair kernel runs nw/2 column transforms, the first of
 //   which carries columns 0 and nw/2 packed as  P0 + i*Pn  (both give real column results).
+#include <cstdlib>
+
 #include "fft_core.h"
 #include "ncc_prep_common.h"
 
@@ -93,6 +95,13 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   unsigned char* item_base = prepared + item * item_bytes;
   cf* spec = reinterpret_cast<cf*>(item_base) + static_cast<size_t>(c) * C::kSpecPerChan;
 
+  if (!is_query) {
+    // 1/sigma slots that no pixel maps to (rows >= ih, columns >= iw, surplus lanes) must read as 0: clear the
+    // channel's slot first; the workgroup barriers below order these stores before the values written later
+    float4* inv4 = reinterpret_cast<float4*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
+                   static_cast<size_t>(c) * (g.inv_per_chan / 4);
+    for (int i = tid; i < g.inv_per_chan / 4; i += kThreads) inv4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
   load_centred(maps, (item * g.channels + c) * static_cast<size_t>(raw_h) * raw_w, raw_w, g.crop, h, w, g.dtype, x0,
                red);
   float scale = 1.0f;
@@ -102,7 +111,6 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     // 1/sigma map in the pair kernel's register order; slots no pixel maps to stay 0.
     float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
                  static_cast<size_t>(c) * g.inv_per_chan;
-    // (the slots no pixel maps to were zeroed by a stream memset ahead of this launch)
     const int nv = g.nv;
     auto store = [&](int n1, int n2, float v) {
       const int pr = n1 >> 1, ab = n1 & 1;
@@ -239,6 +247,14 @@ struct PairArgs {
   int rounds_r;      // row rounds actually needed (<= RR)
   int inv_per_chan;  // floats of 1/sigma per channel
   int accumulate;
+  // team mode (team_size > 0): persistent grid of 8 teams (one per XCD) x team_size resident workgroups
+  int team_size;     // workgroups per team = pairs per epoch
+  int strip_q;       // queries per strip (the last strip may hold fewer)
+  int strips;        // number of query strips
+  int epochs_full;   // epochs of a full strip = ceil(strip_q * ng / team_size)
+  int epochs_total;  // over all strips
+  int sync_polls;    // bound of the soft team barrier
+  int sync_every;    // channels between mid-pair team barriers (0: only at the start of a pair)
 };
 
 // RK = rows of a column transform's output kept in the LDS image (compile-time for the tuned variant: the
@@ -249,19 +265,10 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
                 const unsigned char* __restrict__ pg, size_t g_item_bytes, float* __restrict__ scores,
                 long long ld, long long col0, float* __restrict__ maps_out,
                 const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off,
-                unsigned nyq_off_lds) {
+                unsigned nyq_off_lds, unsigned* __restrict__ team_sync) {
   using GH = typename C::GH;
   using GW = typename C::GW;
-  // ---- which pair ------------------------------------------------------------------------------
   const int nq = g.nq, ng = g.ng;
-  const int tiles_g = ceil_div(ng, kTileG);
-  const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
-  const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
-  const int tq = tile / tiles_g, tg = tile - tq * tiles_g;
-  const int xcd = within & 7, slot = within >> 3;  // 8 XCD groups x 32 slots
-  const int qi = tq * kTileQ + (slot >> 1);
-  const int gi_item = tg * kTileG + 2 * xcd + (slot & 1);
-  if (qi >= nq || gi_item >= ng) return;  // uniform per workgroup
 
   unsigned char* lds = dyn_lds();
   float* red = reinterpret_cast<float*>(lds);
@@ -276,11 +283,9 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   constexpr int NYQ = (2 * C::NH + C::NT - 1) / C::NT;  // Nyquist values prefetched per lane
   static_assert(PF == 1 || PF == RC, "prefetch depth: one unit or one buffer per round");
 
-  const unsigned char* q_item = pq + static_cast<size_t>(qi) * q_item_bytes;
-  const unsigned char* g_item = pg + static_cast<size_t>(gi_item) * g_item_bytes;
-  const cf* qspec = reinterpret_cast<const cf*>(q_item);
-  const cf* gspec = reinterpret_cast<const cf*>(g_item);
-  const float* ginv = reinterpret_cast<const float*>(g_item + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan);
+  const cf* qspec = nullptr;   // set per pair below
+  const cf* gspec = nullptr;
+  const float* ginv = nullptr;
   const int last_c = g.channels - 1;
   const int tid0 = tid;
 
@@ -291,10 +296,6 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   for (int k = tid; k < C::NW; k += C::NT) twt_w[k] = cconj(tw_w[(k / C::TGW) * (k % C::TGW)]);
 
   float acc[RR][NV];
-#pragma unroll
-  for (int r = 0; r < RR; ++r)
-#pragma unroll
-    for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
   const int pairs = g.r_rows / 2;
   const int rs = g.r_stride;                    // row stride of the transposed image RT[j][n1]
   // column outputs p + EH*s with s < s_full are rows < (RK or, for RK == 0, the runtime r_rows) for every p;
@@ -344,6 +345,63 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     }
   };
 
+  // ---- which pairs ------------------------------------------------------------------------------
+  // tile mode: this workgroup's one pair from the 16 x 16 tile mapping above the kernel.
+  // team mode: workgroup = member of team (blockIdx % 8 = XCD); the team walks its share of the epochs, an
+  // epoch being team_size consecutive pairs of a query strip in gallery-major order (so ~strip_q queries x
+  // team_size/strip_q gallery items: every spectrum line has many readers on this L2), and the members
+  // start each pair together (soft barrier) so that those readers are close in time as well.
+  const int team = static_cast<int>(blockIdx.x) & 7, member = static_cast<int>(blockIdx.x) >> 3;
+  unsigned* sync_ctr = team_sync + team * 32;
+  unsigned sync_target = 0;
+  const int syncs_per_pair = g.sync_every > 0 ? ceil_div(g.channels, g.sync_every) : 1;
+  int epoch = 0, epoch_end = 1;
+  if (g.team_size > 0) {
+    epoch = static_cast<int>(static_cast<long long>(g.epochs_total) * team / 8);
+    epoch_end = static_cast<int>(static_cast<long long>(g.epochs_total) * (team + 1) / 8);
+  }
+  for (; epoch < epoch_end; ++epoch) {
+  int qi, gi_item;
+  if (g.team_size > 0) {
+    int strip = epoch / g.epochs_full;
+    strip = strip < g.strips ? strip : g.strips - 1;
+    const int q0 = strip * g.strip_q;
+    const int qn = nq - q0 < g.strip_q ? nq - q0 : g.strip_q;
+    const long long p = static_cast<long long>(epoch - strip * g.epochs_full) * g.team_size + member;
+    gi_item = static_cast<int>(p / qn);
+    qi = q0 + static_cast<int>(p - static_cast<long long>(gi_item) * qn);
+    if (gi_item >= ng) {  // ragged last epoch of a strip: keep the team's count whole and move on
+      if (tid == 0) team_arrive(sync_ctr, static_cast<unsigned>(syncs_per_pair));
+      sync_target += static_cast<unsigned>(syncs_per_pair) * g.team_size;
+      continue;
+    }
+    sync_target += g.team_size;
+    if (tid == 0) {
+      team_arrive(sync_ctr, 1u);
+      team_wait(sync_ctr, sync_target, g.sync_polls);
+    }
+    __syncthreads();
+  } else {
+    const int tiles_g = ceil_div(ng, kTileG);
+    const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
+    const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
+    const int tq = tile / tiles_g, tg = tile - tq * tiles_g;
+    const int xcd = within & 7, slot = within >> 3;  // 8 XCD groups x 32 slots
+    qi = tq * kTileQ + (slot >> 1);
+    gi_item = tg * kTileG + 2 * xcd + (slot & 1);
+    if (qi >= nq || gi_item >= ng) return;  // uniform per workgroup
+  }
+  {
+    const unsigned char* g_item = pg + static_cast<size_t>(gi_item) * g_item_bytes;
+    qspec = reinterpret_cast<const cf*>(pq + static_cast<size_t>(qi) * q_item_bytes);
+    gspec = reinterpret_cast<const cf*>(g_item);
+    ginv = reinterpret_cast<const float*>(g_item + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan);
+  }
+#pragma unroll
+  for (int r = 0; r < RR; ++r)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
+
   issue_nyq(0);
   if constexpr (PF == RC) {
 #pragma unroll
@@ -355,6 +413,13 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   __syncthreads();
 
   for (int c = 0; c < g.channels; ++c) {
+    if (g.sync_every > 0 && c > 0 && c % g.sync_every == 0) {  // team mode only (sync_every is 0 otherwise)
+      sync_target += g.team_size;
+      if (tid == 0) {  // the other waves run on to the next workgroup barrier
+        team_arrive(sync_ctr, 1u);
+        team_wait(sync_ctr, sync_target, g.sync_polls);
+      }
+    }
     // lane coordinates, re-derived from an opaque copy of the lane id every channel (see spr::opaque)
     const int tidv = opaque(tid0);
     const int gc = tidv / C::TGH, tc = tidv - gc * C::TGH;  // column-pass group / lane in group
@@ -502,6 +567,7 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     const float prev = g.accumulate ? *dst : 0.0f;
     *dst = s > prev ? s : prev;
   }
+  }  // epochs
 }
 
 // ============================================================================================
@@ -560,7 +626,7 @@ struct FftEntry {
   size_t (*pair_lds_total)(const NccGeom&);
   int (*prep)(const NccGeom&, bool, const void*, int64_t, void*, const cf*, const cf*, hipStream_t);
   int (*pair)(const NccGeom&, bool, const void*, int64_t, const void*, int64_t, float*, int64_t, int64_t, int, float*,
-              const cf*, const cf*, hipStream_t);
+              const cf*, const cf*, unsigned*, hipStream_t);
 };
 
 template <class C>
@@ -575,17 +641,6 @@ int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* p
   const size_t item_bytes = is_query ? prepared_query_item_bytes(g, SPR_NCC_FFT) : prepared_gallery_item_bytes(g, SPR_NCC_FFT);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kLdsLimit);
-  if (!is_query) {
-    // 1/sigma slots that no pixel maps to (rows >= ih, columns >= iw, surplus lanes) must read as 0
-    // (one strided fill: n rows of the items' 1/sigma part, pitch = item size)
-    const size_t spec_bytes = sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan;
-    if (hipMemset2DAsync(static_cast<unsigned char*>(prepared) + spec_bytes, item_bytes, 0,
-                         sizeof(float) * static_cast<size_t>(g.channels) * g.inv_per_chan, static_cast<size_t>(n),
-                         stream) != hipSuccess) {
-      set_error("hipMemset2DAsync(1/sigma) failed");
-      return SPR_ERR_HIP;
-    }
-  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads),
                      l.total, stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes, tw_h,
                      tw_w, static_cast<unsigned>(l.x0_off), static_cast<unsigned>(l.f_off),
@@ -594,24 +649,65 @@ int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* p
   return check_launch("prep_fft_kernel");
 }
 
+// Team mode is opt-in (SPR_NCC_TEAM=1; SPR_NCC_TEAM_POLLS / SPR_NCC_TEAM_EVERY tune the soft barrier).
+// Measured at Q=100 x G=1500 on conv3_3 maps: L2 hit rate 57 % -> 83 %, memory-side traffic 21.4 -> 8.6 MB per
+// pair, but 4 % SLOWER (237 k against 248 k pairs/s): the kernel is bound by LDS/VALU latency at two waves per
+// SIMD, not by memory, and every barrier waits for the slowest of 64 workgroups.  The tile schedule stays
+// the default; the team schedule is the one to use when HBM bandwidth is shared with other work.
+constexpr int kTeamCounters = 8 * 32;  // one 128-byte line per team
+
+inline int env_int(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : fallback;
+}
+
 template <class C, int RR, int KW, int PF, int RK>
 int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
-                int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, hipStream_t stream) {
+                int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, unsigned* team_sync,
+                hipStream_t stream) {
   const PairFftLds l = pair_fft_lds<C>(g);
   const int64_t tiles = static_cast<int64_t>(ceil_div(static_cast<int>(nq), kTileQ)) * ceil_div(static_cast<int>(ng), kTileG);
   PairArgs a{};
   a.channels = g.channels; a.nq = static_cast<int>(nq); a.ng = static_cast<int>(ng);
   a.ih = g.ih; a.iw = g.iw; a.r_rows = g.r_rows; a.r_stride = g.r_stride; a.rounds_r = g.rounds_r;
   a.inv_per_chan = g.inv_per_chan; a.accumulate = accumulate;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK>), dim3(static_cast<unsigned>(tiles * kTileQ * kTileG)),
+  const void* kernel = reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK>);
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+  unsigned grid = static_cast<unsigned>(tiles * kTileQ * kTileG);
+  // ---- team mode: a persistent grid that exactly fills the device, 8 teams of co-resident workgroups ----
+  int per_cu = 0, cus = 0, dev = 0;
+  if (team_sync && !maps_out && hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_fft_kernel<C, RR, KW, PF, RK>, C::NT, l.total) == hipSuccess &&
+      per_cu > 0 && cus >= 8) {
+    const int team_size = cus / 8 * per_cu;
+    if (env_int("SPR_NCC_TEAM", 0) == 1) {
+      const int strips = ceil_div(static_cast<int>(nq), 16);
+      a.team_size = team_size;
+      a.strips = strips;
+      a.strip_q = ceil_div(static_cast<int>(nq), strips);
+      a.strips = ceil_div(static_cast<int>(nq), a.strip_q);
+      a.epochs_full = static_cast<int>((static_cast<int64_t>(a.strip_q) * ng + team_size - 1) / team_size);
+      const int q_last = static_cast<int>(nq) - (a.strips - 1) * a.strip_q;
+      a.epochs_total = (a.strips - 1) * a.epochs_full + static_cast<int>((static_cast<int64_t>(q_last) * ng + team_size - 1) / team_size);
+      a.sync_polls = env_int("SPR_NCC_TEAM_POLLS", 256);
+      a.sync_every = env_int("SPR_NCC_TEAM_EVERY", 32);
+      if (a.sync_every < 0) a.sync_every = 0;
+      grid = 8u * static_cast<unsigned>(team_size);
+      if (hipMemsetAsync(team_sync, 0, sizeof(unsigned) * kTeamCounters, stream) != hipSuccess) {
+        set_error("hipMemsetAsync(team counters) failed");
+        return SPR_ERR_HIP;
+      }
+    }
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK>), dim3(grid),
                      dim3(C::NT), l.total, stream, a, static_cast<const unsigned char*>(pq),
                      prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
                      prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores,
                      static_cast<long long>(ld), static_cast<long long>(col0), maps_out, tw_h, tw_w,
                      static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off),
-                     static_cast<unsigned>(l.nyq_off));
+                     static_cast<unsigned>(l.nyq_off), team_sync);
+  (void)kernel;
   return check_launch("pair_fft_kernel");
 }
 
@@ -619,12 +715,12 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
 template <class C, int PFA>
 int pair_t(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
-           hipStream_t stream) {
+           unsigned* team_sync, hipStream_t stream) {
   if (tuned)
     return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>()>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out,
-                                                                tw_h, tw_w, stream);
+                                                                tw_h, tw_w, team_sync, stream);
   return pair_launch<C, C::RR_B, C::KW_B, 1, 0>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
-                                                stream);
+                                                team_sync, stream);
 }
 
 template <class C, int PFA>
@@ -718,11 +814,11 @@ int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n
 
 int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
-                    hipStream_t stream) {
+                    unsigned* team_sync, hipStream_t stream) {
   if (nq == 0 || ng == 0) return SPR_OK;
   const FftEntry* e = find_entry(g.nh, g.nw);
   if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
-  return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, stream);
+  return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, team_sync, stream);
 }
 
 }  // namespace spr

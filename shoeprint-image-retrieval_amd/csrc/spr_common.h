@@ -68,7 +68,7 @@ int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n
                     const cf* tw_w, hipStream_t stream);
 int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
-                    hipStream_t stream);
+                    unsigned* team_sync, hipStream_t stream);  // team_sync: 8 x 32 counters, or null (tile mode only)
 bool fft_geometry(NccGeom& g, bool pow2_only);  // fills the FFT fields; false if no instantiated kernel fits
 bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps do not fit LDS
 

@@ -39,6 +39,21 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// ---- soft team barrier (locality hint, never a correctness dependency) ------------------------------
+// Workgroups that share an L2 announce themselves on a monotonic counter and wait, for a BOUNDED number of
+// polls, until the whole team has arrived.  A team member that is late (or not resident at all) only costs
+// the others the timeout: every wave leaves the wait, and results never depend on it.
+__device__ __forceinline__ void team_arrive(unsigned* counter, unsigned n) {
+  __hip_atomic_fetch_add(counter, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void team_wait(unsigned* counter, unsigned target, int max_polls) {
+  for (int i = 0; i < max_polls; ++i) {
+    const unsigned seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (static_cast<int>(seen - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 // ---- complex arithmetic on packed fp32 (a complex number = one 64-bit VGPR pair {re, im}) -----------
 // hipcc materialises i*x (swap halves, flip one sign) as v_mov + v_xor before a packed op; the VOP3P
 // operand modifiers do it for free.  op_sel / op_sel_hi pick the source half feeding the low / high

@@ -242,6 +242,12 @@ static inline hipError_t hipMemset2DAsync(void* d, size_t pitch, int v, size_t w
   return hipSuccess;
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// a pretend device of 16 CUs with room for 2 workgroups each (persistent-grid sizing)
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 16; return hipSuccess; }
+template <class F>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }

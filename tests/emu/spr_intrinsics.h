@@ -40,6 +40,10 @@ inline int shfl(int v, int src) { return exchange(v, src); }
 
 inline int opaque(int v) { return v; }
 
+// soft team barrier: workgroups run one after another here, so the wait is the timeout case (returns at once)
+inline void team_arrive(unsigned* counter, unsigned n) { __atomic_fetch_add(counter, n, __ATOMIC_RELAXED); }
+inline void team_wait(unsigned*, unsigned, int) {}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 inline f32x2 pk_add_i(f32x2 e, f32x2 o) { return f32x2{e.x - o.y, e.y + o.x}; }
 inline f32x2 pk_sub_i(f32x2 e, f32x2 o) { return f32x2{e.x + o.y, e.y - o.x}; }

@@ -109,6 +109,25 @@ def check_shape_case(scorer, case, tol=TIGHT):
     np.testing.assert_allclose(mat, ref, atol=tol, rtol=0)
 
 
+def check_team_mode(scorer, monkeypatch):
+    """The pair kernel's persistent "team" schedule (opt-in: SPR_NCC_TEAM=1)
+    scores exactly what the one-pair-per-workgroup schedule does: ragged epochs, several query strips."""
+    for nq, ng, case in ((5, 7, (2, 32, 16, 32, 16)), (19, 3, (1, 20, 12, 24, 14)), (1, 9, (2, 32, 16, 32, 16))):
+        c, qh, qw, gh, gw = case
+        q = [synth.gallery_features(31, 100 + i, c, qh, qw) for i in range(nq)]
+        g = [synth.gallery_features(31, i, c, gh, gw) for i in range(ng)]
+        monkeypatch.setenv("SPR_NCC_TEAM", "0")
+        tiles = scorer.score_matrix(q, g)
+        monkeypatch.setenv("SPR_NCC_TEAM", "1")
+        team = scorer.score_matrix(q, g)
+        monkeypatch.setenv("SPR_NCC_TEAM_EVERY", "1")  # a soft barrier every channel as well
+        team_every = scorer.score_matrix(q, g)
+        monkeypatch.delenv("SPR_NCC_TEAM_EVERY")
+        np.testing.assert_array_equal(team, tiles)
+        np.testing.assert_array_equal(team_every, tiles)
+        np.testing.assert_allclose(team, oracle.similarity_matrix(q, g, precise=True), atol=TIGHT, rtol=0)
+
+
 def check_rank_kernel(scorer):
     rng = np.random.default_rng(5)
     for nq, ng in [(1, 1), (3, 7), (5, 300), (2, 1500)]:

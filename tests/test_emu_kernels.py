@@ -48,6 +48,10 @@ def test_emu_conv3_sized_maps_fft(case, method):
     pc.check_shape_case(emu_scorer(method), case)
 
 
+def test_emu_team_schedule(monkeypatch):
+    pc.check_team_mode(emu_scorer("fft"), monkeypatch)
+
+
 def test_emu_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 

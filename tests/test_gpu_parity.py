@@ -67,6 +67,10 @@ def test_golden_conv3_shaped_compare_maps(scorer):
     pc.check_golden_compare_maps(scorer, "conv3")
 
 
+def test_team_schedule(fft_scorer, monkeypatch):
+    pc.check_team_mode(fft_scorer, monkeypatch)
+
+
 def test_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 
@@ -207,7 +211,7 @@ def test_run_driver_on_an_image_directory(tmp_path, capsys):
     """run_mi355x.main(run.toml) on a two-cluster Gallery/Query directory == dataloader -> oracle chain."""
     import dataset_util
     import run_mi355x
-    from oracle import clahe_oracle, vgg_oracle
+    from oracle import clahe_oracle, ncc_oracle, vgg_oracle
     from shoeprint_image_retrieval_amd import synth
     from shoeprint_image_retrieval_amd.dataloader import Dataloader
 
@@ -226,5 +230,5 @@ def test_run_driver_on_an_image_directory(tmp_path, capsys):
     for queries, gallery, matches, block in Dataloader(cfg):
         params = synth.vgg16_parameters(1234, vgg_oracle.conv_shapes(block))
         feats = lambda ims: [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), block, params) for im in ims]
-        want += [int(r) for r in oracle.compare_maps(feats(queries), feats(gallery), matches, cfg)]
+        want += [int(r) for r in ncc_oracle.compare_maps(feats(queries), feats(gallery), matches, cfg)]
     assert got == want

@@ -19,9 +19,20 @@ def short(name: str) -> str:
     return re.split(r"[<(]", name)[0].strip()
 
 
+def _db_rows(d, query):
+    import sqlite3
+    for f in glob.glob(os.path.join(d, "**", "*results.db"), recursive=True):
+        yield from sqlite3.connect(f).execute(query)
+
+
 def kernel_stats(d):
     rows = {}
-    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+    for name, calls, total_ns, avg_ns in _db_rows(d, "select name, total_calls, total_duration*1000, average*1000 from top_kernels"):
+        k = short(name)  # the rocpd view reports microseconds
+        e = rows.setdefault(k, {"kernel": k, "calls": 0, "total_ms": 0.0, "variants": []})
+        e["calls"] += calls; e["total_ms"] += total_ns / 1e6
+        e["variants"].append({"name": name[:160], "calls": calls, "avg_ms": avg_ns / 1e6})
+    for f in ([] if rows else glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             k = short(r["Name"])
             e = rows.setdefault(k, {"kernel": k, "calls": 0, "total_ms": 0.0, "variants": []})
@@ -37,7 +48,10 @@ def kernel_stats(d):
 
 def counter_sums(d, counter):
     sums = {}
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for name, disp, value in _db_rows(d, f"select kernel_name, dispatch_id, value from counters_collection where counter_name = '{counter}'"):
+        e = sums.setdefault(short(name), {"sum": 0.0, "dispatches": set()})
+        e["sum"] += float(value); e["dispatches"].add(disp)
+    for f in ([] if sums else glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
