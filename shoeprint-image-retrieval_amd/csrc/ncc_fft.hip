@@ -260,7 +260,7 @@ struct PairArgs {
 // RK = rows of a column transform's output kept in the LDS image (compile-time for the tuned variant: the
 // stage-2 outputs beyond it are dead code and the stores need no per-row test; 0 = runtime r_rows)
 template <class C, int RR, int KW, int PF, int RK>
-__global__ void __launch_bounds__(C::NT, 2)
+__global__ void __launch_bounds__(C::NT, (C::NT == 64 && RK > 0) ? 4 : 2)
 pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
                 const unsigned char* __restrict__ pg, size_t g_item_bytes, float* __restrict__ scores,
                 long long ld, long long col0, float* __restrict__ maps_out,
@@ -732,14 +732,19 @@ constexpr FftEntry entry() {
 }
 
 // (E, TG) factorisations: 256 = 16*16, 192 = 12*16, 128 = 16*8, 96 = 12*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
-// (96 x 48 and 48 x 24 for the conv4_3 / conv5_3 maps were measured SLOWER than 128 x 64 / 64 x 32: their
-// 8- and 4-lane groups fill only 50-75 % of the 256 lanes and per-channel fixed costs dominate there.)
+// The workgroup size follows the grid: a transform group is TG lanes, and a 256-lane workgroup on a small
+// grid leaves most groups idle (48 x 24 on 256 lanes was slower than 64 x 32).  Measured on an MI355X
+// (kernel only): conv5_3 maps [512,32,16]  408 k pairs/s (64 x 32, 256 lanes) -> 879 k (64 x 32, one wave)
+// -> 1.22 M (48 x 24, one wave);  conv4_3 maps [512,64,32]  255 k (128 x 64, 256 lanes) -> 295 k (96 x 48,
+// 256 lanes) -> 307 k (96 x 48, 192 lanes);  one wave per pair on 128 x 64 spills: 69 k.
 //                 EH TGH EW TGW  NT KWA RRA      prefetch buffers of the tuned variant
 const FftEntry kEntries[] = {
-    entry<Cfg<8, 4, 4, 4, 256, 2, 1>, 1>(),       // 32 x 16
-    entry<Cfg<8, 4, 8, 4, 256, 2, 1>, 1>(),       // 32 x 32
-    entry<Cfg<8, 8, 8, 4, 256, 2, 1>, 1>(),       // 64 x 32
+    entry<Cfg<8, 4, 4, 4, 64, 2, 1>, 1>(),        // 32 x 16   (grids this small: one WAVE per pair, no workgroup
+    entry<Cfg<8, 4, 8, 4, 64, 2, 1>, 1>(),        // 32 x 32    barriers, up to 16 independent waves per CU)
+    entry<Cfg<12, 4, 6, 4, 64, 2, 1>, 1>(),       // 48 x 24: conv5_3 / ResNet layer3 maps of a 512x256 print
+    entry<Cfg<8, 8, 8, 4, 64, 2, 1>, 1>(),        // 64 x 32: conv5_3 / ResNet layer3 maps; one WAVE per pair
     entry<Cfg<8, 8, 8, 8, 256, 4, 1>, 1>(),       // 64 x 64
+    entry<Cfg<12, 8, 6, 8, 192, 5, 2>, 1>(),      // 96 x 48: conv4_3 maps; 3 waves = its 24 columns x 8 lanes exactly
     entry<Cfg<16, 8, 8, 8, 256, 4, 1>, 1>(),      // 128 x 64
     entry<Cfg<16, 8, 16, 8, 256, 4, 1>, 1>(),     // 128 x 128
     entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),    // 192 x 96: conv3_3 of a 512x256 print; two workgroups per CU

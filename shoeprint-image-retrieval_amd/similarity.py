@@ -31,6 +31,16 @@ _METHODS = {"auto": NCC_AUTO, "fft": NCC_FFT, "direct": NCC_DIRECT, "fft_pow2": 
 _DTYPES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float16): _lib.F16}
 
 
+def _dtype_code(dtype) -> tuple[int, str]:
+    """(spr_dtype, cache key) of a feature storage type: numpy float32 / float16, or bfloat16 given as the
+    string "bfloat16", a torch.bfloat16, or uint16 bit patterns (numpy has no bfloat16)."""
+    name = str(dtype).replace("torch.", "")
+    if name in ("bfloat16", "bf16", "uint16", "<class 'numpy.uint16'>"):
+        return _lib.BF16, "bf16"
+    d = np.dtype(name if name in ("float32", "float16") else dtype)
+    return _DTYPES[d], d.str
+
+
 class _Plan:
     """Owns one spr_ncc_plan (one (query shape, gallery shape) class)."""
 
@@ -100,10 +110,11 @@ class NccScorer:
     # ------------------------------------------------------------------ plans
     def plan(self, channels: int, q_hw, g_hw, dtype=np.float32, crop: int | None = None) -> _Plan:
         crop = self.crop if crop is None else crop
-        key = (channels, tuple(q_hw), tuple(g_hw), np.dtype(dtype).str, crop, self.method)
+        code, dkey = _dtype_code(dtype)
+        key = (channels, tuple(q_hw), tuple(g_hw), dkey, crop, self.method)
         p = self._plans.get(key)
         if p is None:
-            p = _Plan(self.lib, channels, q_hw, g_hw, crop, _DTYPES[np.dtype(dtype)], self.method)
+            p = _Plan(self.lib, channels, q_hw, g_hw, crop, code, self.method)
             self._plans[key] = p
         return p
 
@@ -145,13 +156,17 @@ class NccScorer:
 
     def scores_device(self, q_dev, g_dev, scores=None, accumulate_max: bool = False, plan: _Plan | None = None):
         """[Q,G] float32 score matrix (device) of a uniform query batch [Q,C,h,w] against a uniform
-        gallery batch [G,C,h',w'], both already in HBM.  One step of the hot path."""
+        gallery batch [G,C,h',w'], both already in HBM.  One step of the hot path.  The storage type is
+        taken from the buffers: float32, float16, or bfloat16 (torch.bfloat16 or uint16 bit patterns); the
+        arithmetic is float32 / float64 as ever."""
         nq, c, qh, qw = self.dev.shape(q_dev)
         ng, c2, gh, gw = self.dev.shape(g_dev)
         if c != c2:
             raise ValueError(f"channel mismatch: queries {c}, gallery {c2}")
         if plan is None:
-            plan = self.plan(c, (qh, qw), (gh, gw))
+            if str(q_dev.dtype) != str(g_dev.dtype):
+                raise ValueError(f"storage type mismatch: queries {q_dev.dtype}, gallery {g_dev.dtype}")
+            plan = self.plan(c, (qh, qw), (gh, gw), dtype=q_dev.dtype)
         if scores is None:
             scores = self.dev.zeros((nq, ng), np.float32)
         if nq == 0 or ng == 0:
@@ -236,6 +251,18 @@ class NccScorer:
                     block = out[np.ix_(q_idx, idx)]
                     out[np.ix_(q_idx, idx)] = np.maximum(block, sub_h)
         return out
+
+    def multi_layer_score_matrix(self, layers) -> np.ndarray:
+        """Mean over feature layers of the per-layer [Q,G] matrices (e.g. conv3_3 +
+        conv4_3 + conv5_3 maps of the same items; build-defined, the reference scores one layer).
+        ``layers`` = [(q_dev [Q,C_l,h_l,w_l], g_dev [G,C_l,h_l,w_l]), ...] resident in HBM."""
+        total = None
+        for q_dev, g_dev in layers:
+            s = self.dev.to_host(self.scores_device(q_dev, g_dev))
+            total = s.astype(np.float32) if total is None else total + s
+        if total is None:
+            raise ValueError("no feature layers given")
+        return total / np.float32(len(layers))
 
     def ranks(self, scores_host: np.ndarray, matching_pairs: Sequence[int]) -> np.ndarray:
         nq, ng = scores_host.shape

@@ -128,3 +128,15 @@ def vgg16_parameters(seed: int, conv_shapes) -> list[tuple[np.ndarray, np.ndarra
         b = irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 2 * i + 1), np.arange(cout, dtype=np.int64)).astype(np.float32)
         params.append((w, b * np.float32(0.05 / 37837.0)))
     return params
+
+
+def bfloat16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bit patterns (uint16), round to nearest even — the storage form the scorer
+    accepts for bf16 features (numpy has no bfloat16 type)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    rounded = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return rounded.astype(np.uint16)
+
+
+def from_bfloat16_bits(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)

@@ -128,6 +128,36 @@ def check_team_mode(scorer, monkeypatch):
         np.testing.assert_allclose(team, oracle.similarity_matrix(q, g, precise=True), atol=TIGHT, rtol=0)
 
 
+def check_config3_bf16_resnet_layer3(scorer, channels):
+    """BASELINE config 3 in miniature: ResNet50-layer3-shaped maps [C,32,16] stored as bfloat16 (extractor
+    bypassed, half-normal synthetic features as SURVEY §8d says).  Parity = the oracle on the same rounded
+    features upcast to float32; the arithmetic stays float32/float64."""
+    nq, ng = 3, 5
+    g = [np.maximum(synth.gallery_features(41, i, channels, 32, 16), 0) for i in range(ng)]
+    q = [np.maximum(synth.query_features(41, i, i, channels, 32, 16), 0) for i in range(nq)]
+    qb, gb = synth.bfloat16_bits(np.stack(q)), synth.bfloat16_bits(np.stack(g))
+    dev = scorer.dev
+    got = dev.to_host(scorer.scores_device(dev.to_device(qb), dev.to_device(gb)))
+    ref = oracle.similarity_matrix(list(synth.from_bfloat16_bits(qb)), list(synth.from_bfloat16_bits(gb)), precise=True)
+    np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
+    assert (got.argmax(axis=1) == np.arange(nq)).all()  # each query still finds its own print
+
+
+def check_config5_multi_layer_fp16(scorer, channels):
+    """BASELINE config 5 in miniature: conv3_3 + conv4_3 + conv5_3 shaped maps in float16, score = mean of the
+    three get_similarity values (build-defined)."""
+    nq, ng = 2, 3
+    dev = scorer.dev
+    layers, refs = [], []
+    for k, (c, h, w) in enumerate(zip(channels, (128, 64, 32), (64, 32, 16))):
+        g = np.stack([synth.gallery_features(50 + k, i, c, h, w) for i in range(ng)]).astype(np.float16)
+        q = np.stack([synth.query_features(50 + k, i, i, c, h, w) for i in range(nq)]).astype(np.float16)
+        layers.append((dev.to_device(q), dev.to_device(g)))
+        refs.append(oracle.similarity_matrix(list(q.astype(np.float32)), list(g.astype(np.float32)), precise=True))
+    got = scorer.multi_layer_score_matrix(layers)
+    np.testing.assert_allclose(got, np.mean(refs, axis=0), atol=TIGHT, rtol=0)
+
+
 def check_rank_kernel(scorer):
     rng = np.random.default_rng(5)
     for nq, ng in [(1, 1), (3, 7), (5, 300), (2, 1500)]:

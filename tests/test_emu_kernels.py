@@ -88,8 +88,10 @@ def test_emu_auto_method_and_errors():
     assert sc.plan(4, (16, 12), (16, 12)).fft_size == (32, 16)
     assert sc.plan(256, (128, 64), (128, 64)).fft_size == (192, 96)   # VGG16 conv3_3 of a 512x256 print: 3*2^k grid
     assert emu_scorer("fft_pow2").plan(256, (128, 64), (128, 64)).fft_size == (256, 128)
-    assert sc.plan(512, (64, 32), (64, 32)).fft_size == (128, 64)     # conv4_3
-    assert sc.plan(512, (32, 16), (32, 16)).fft_size == (64, 32)      # conv5_3
+    assert sc.plan(512, (64, 32), (64, 32)).fft_size == (96, 48)      # conv4_3
+    assert emu_scorer("fft_pow2").plan(512, (64, 32), (64, 32)).fft_size == (128, 64)
+    assert sc.plan(512, (32, 16), (32, 16)).fft_size == (48, 24)      # conv5_3: 3*2^k grid, one wave per pair
+    assert emu_scorer("fft_pow2").plan(512, (32, 16), (32, 16)).fft_size == (64, 32)
     with pytest.raises(_lib.SprError) as e:
         sc.plan(4, (4, 4), (16, 12))  # vanishes under the 2-pixel crop
     assert e.value.code == -2
@@ -119,6 +121,12 @@ def test_float16_feature_storage():
     sc.score_prepared(plan, pq, 2, pg, 3, scores, 3, 0)
     ref = oracle.similarity_matrix(list(q16.astype(np.float32)), list(g16.astype(np.float32)), precise=True)
     np.testing.assert_allclose(dev.to_host(scores), ref, atol=pc.TIGHT)
+
+
+def test_emu_reduced_precision_configs():
+    sc = emu_scorer("fft")
+    pc.check_config3_bf16_resnet_layer3(sc, channels=16)
+    pc.check_config5_multi_layer_fp16(sc, channels=(2, 4, 4))
 
 
 # ------------------------------------------------------------------------- real library: ABI only

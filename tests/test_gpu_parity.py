@@ -71,6 +71,14 @@ def test_team_schedule(fft_scorer, monkeypatch):
     pc.check_team_mode(fft_scorer, monkeypatch)
 
 
+def test_config3_bf16_resnet_layer3_maps(fft_scorer):
+    pc.check_config3_bf16_resnet_layer3(fft_scorer, channels=1024)
+
+
+def test_config5_multi_layer_fp16(fft_scorer):
+    pc.check_config5_multi_layer_fp16(fft_scorer, channels=(256, 512, 512))
+
+
 def test_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 
