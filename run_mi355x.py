@@ -9,9 +9,11 @@ the S-scores of that cluster against the whole-data-set totals.  Additionally pr
 clusters at the end.
 """
 
+import os
 import sys
 
 from shoeprint_image_retrieval_amd.config import load_config
+from shoeprint_image_retrieval_amd import feature_cache
 from shoeprint_image_retrieval_amd.dataloader import Dataloader
 from shoeprint_image_retrieval_amd.network import Model
 from shoeprint_image_retrieval_amd.parse_results import cmp_all, mean_average_precision, rank1
@@ -23,11 +25,24 @@ def main(config_file: str = "run.toml") -> list[int]:
     dataloader = Dataloader(config)
     print(f"{dataloader.num_clusters} clusters of image sizes found.")
     all_ranks: list[int] = []
-    for shoemark_images, shoeprint_images, matching_shoeprint_ids, block in dataloader:
+    cache_dir = config["mi355x"].get("gallery_cache", "")
+    for cluster, (shoemark_images, shoeprint_images, matching_shoeprint_ids, block) in enumerate(dataloader):
         print(f"Cluster has {len(shoemark_images)} items.")
         model = Model(config, block)
         shoemark_features = model.get_multiple_feature_maps(shoemark_images)
-        shoeprint_features = model.get_multiple_feature_maps(shoeprint_images)
+        # gallery features depend only on what is in `key`: keep them across runs when [mi355x].gallery_cache is set
+        key = {"files": dataloader.shoeprint_files, "scale": dataloader.scales[cluster], "block": block,
+               "crop": list(config["dataset"]["crop"]), "model": dict(config["model"]),
+               "weights": config["mi355x"].get("weights", "")}
+        path = os.path.join(cache_dir, f"gallery_block{block}_cluster{cluster}.f32") if cache_dir else ""
+        shoeprint_features = feature_cache.load_features(path, key) if path else None
+        if shoeprint_features is None:
+            shoeprint_features = model.get_multiple_feature_maps(shoeprint_images)
+            if path:
+                os.makedirs(cache_dir, exist_ok=True)
+                feature_cache.save_features(path, shoeprint_features, key)
+        else:
+            print(f"Gallery features from {path}")
         print("Calculating ranks:")
         ranks = compare_maps(shoemark_features, shoeprint_features, matching_shoeprint_ids, config, progress=True)
         cmp_all(list(ranks), total_shoeprints=len(dataloader.shoeprint_files),

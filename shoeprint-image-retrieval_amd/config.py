@@ -45,6 +45,7 @@ class Mi355xConfig(TypedDict, total=False):
     ncc_method: str
     max_prepared_gib: float
     weights: str
+    gallery_cache: str  # directory for persisted gallery features (feature_cache.py); "" = off
 
 
 class Config(TypedDict, total=False):
@@ -54,7 +55,8 @@ class Config(TypedDict, total=False):
     mi355x: Mi355xConfig
 
 
-MI355X_DEFAULTS: dict[str, Any] = {"dtype": "float32", "ncc_method": "auto", "max_prepared_gib": 0.0, "weights": ""}
+MI355X_DEFAULTS: dict[str, Any] = {"dtype": "float32", "ncc_method": "auto", "max_prepared_gib": 0.0, "weights": "",
+                                   "gallery_cache": ""}
 
 
 def normalise(raw: dict) -> Config:

@@ -53,6 +53,7 @@ struct spr_ncc_plan {
   spr::cf* tw_h = nullptr;  // device: exp(-2*pi*i*k/nh), k < nh
   spr::cf* tw_w = nullptr;  // device: exp(-2*pi*i*k/nw), k < nw
   unsigned* team_sync = nullptr;  // device: arrival counters of the pair kernel's 8 workgroup teams
+  spr::FftWorkspace ws{nullptr, 0};  // device: scratch of the "big" geometries (maps beyond LDS)
 };
 
 using namespace spr;
@@ -139,6 +140,15 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
       set_error("hipMalloc(team counters) failed");
       rc = SPR_ERR_HIP;
     }
+    const size_t ws_bytes = fft_workspace_bytes(p->geom);
+    if (rc == SPR_OK && ws_bytes > 0) {
+      if (hipMalloc(&p->ws.base, ws_bytes) != hipSuccess) {
+        set_error("hipMalloc(%zu bytes of FFT workspace) failed", ws_bytes);
+        rc = SPR_ERR_WORKSPACE;
+      } else {
+        p->ws.bytes = ws_bytes;
+      }
+    }
     if (rc != SPR_OK) { spr_ncc_plan_destroy(p); return rc; }
   }
   *plan_out = p;
@@ -150,6 +160,7 @@ extern "C" void spr_ncc_plan_destroy(spr_ncc_plan* plan) {
   if (plan->tw_h) (void)hipFree(plan->tw_h);
   if (plan->tw_w) (void)hipFree(plan->tw_w);
   if (plan->team_sync) (void)hipFree(plan->team_sync);
+  if (plan->ws.base) (void)hipFree(plan->ws.base);
   delete plan;
 }
 
@@ -179,7 +190,7 @@ static int prepare(spr_ncc_plan* plan, bool is_query, const void* maps, int64_t 
   if (!maps || !prepared) { set_error("%s: null pointer", who); return SPR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan->method == SPR_NCC_FFT)
-    return launch_prep_fft(plan->geom, is_query, maps, n, prepared, plan->tw_h, plan->tw_w, s);
+    return launch_prep_fft(plan->geom, is_query, maps, n, prepared, plan->tw_h, plan->tw_w, plan->ws, s);
   return launch_prep_direct(plan->geom, is_query, maps, n, prepared, s);
 }
 
@@ -202,7 +213,7 @@ extern "C" int spr_ncc_score(spr_ncc_plan* plan, const void* pq, int64_t nq, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan->method == SPR_NCC_FFT)
     return launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
-                           plan->tw_w, plan->team_sync, s);
+                           plan->tw_w, plan->team_sync, plan->ws, s);
   return launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
 }
 
@@ -210,6 +221,7 @@ extern "C" int spr_ncc_maps(spr_ncc_plan* plan, const void* pq, const void* pg, 
   if (!plan || !pq || !pg || !maps_out) { set_error("spr_ncc_maps: null pointer"); return SPR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan->method == SPR_NCC_FFT)
-    return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w, nullptr, s);
+    return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w,
+                           plan->geom.big ? plan->team_sync : nullptr, plan->ws, s);
   return launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
 }

@@ -72,18 +72,24 @@ inline int rt_stride(int r_rows) { return r_rows + ((8 - r_rows % 32) + 32) % 32
 // ============================================================================================
 // Forward (prep) kernel.  grid = (channels, n_items), kThreads lanes
 // ============================================================================================
-template <class C>
+// BIG: maps too large for LDS.  The centred map, the two float64 tables and the row-pass output then live in a
+// per-workgroup slot of a global workspace (x0_off / f_off / sat2_off are offsets into the slot); only the
+// exchange buffers stay in LDS.  Same code, same arithmetic - the slot is L2-resident scratch.
+template <class C, bool BIG>
 __global__ void __launch_bounds__(kThreads)
 prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                 size_t item_bytes, const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned x0_off,
-                unsigned f_off, unsigned xbuf_off, unsigned zbuf_off, unsigned sat2_off, int f_stride) {
+                unsigned f_off, unsigned xbuf_off, unsigned zbuf_off, unsigned sat2_off, int f_stride,
+                unsigned char* __restrict__ ws, size_t slot_bytes) {
   using GH = typename C::GH;
   using GW = typename C::GW;
   unsigned char* lds = dyn_lds();
+  unsigned char* big = lds;
+  if constexpr (BIG) big = ws + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * slot_bytes;
   double* red = reinterpret_cast<double*>(lds);
-  float* x0 = reinterpret_cast<float*>(lds + x0_off);
-  double* sat = reinterpret_cast<double*>(lds + f_off);  // dead before F is written
-  cf* F = reinterpret_cast<cf*>(lds + f_off);
+  float* x0 = reinterpret_cast<float*>(big + x0_off);
+  double* sat = reinterpret_cast<double*>(big + f_off);  // dead before F is written
+  cf* F = reinterpret_cast<cf*>(big + f_off);
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
   cf* zbuf = reinterpret_cast<cf*>(lds + zbuf_off);
   const int tid = static_cast<int>(threadIdx.x);
@@ -122,7 +128,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
       inv[((rr * (nv / 4) + (e2 >> 2)) * C::NT + lane) * 4 + (e2 & 3)] = v;
     };
     if (sat2_off != 0) {
-      inv_sigma_map_fused(x0, h, w, g.th, g.tw, sat, reinterpret_cast<double*>(lds + sat2_off), store);
+      inv_sigma_map_fused(x0, h, w, g.th, g.tw, sat, reinterpret_cast<double*>(big + sat2_off), store);
     } else {
       inv_sigma_map(x0, h, w, g.th, g.tw, sat, [&](int i, float v) { store(i / w, i % w, v); });
     }
@@ -259,13 +265,16 @@ struct PairArgs {
 
 // RK = rows of a column transform's output kept in the LDS image (compile-time for the tuned variant: the
 // stage-2 outputs beyond it are dead code and the stores need no per-row test; 0 = runtime r_rows)
-template <class C, int RR, int KW, int PF, int RK>
-__global__ void __launch_bounds__(C::NT, (C::NT == 64 && RK > 0) ? 4 : 2)
+// BIG: the intermediate image does not fit LDS; it lives in this workgroup's slot of a global workspace (the
+// launch is then always the persistent team grid, one slot per resident workgroup).
+template <class C, int RR, int KW, int PF, int RK, bool BIG>
+__global__ void __launch_bounds__(C::NT, BIG ? 1 : ((C::NT == 64 && RK > 0) ? 4 : 2))
 pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
                 const unsigned char* __restrict__ pg, size_t g_item_bytes, float* __restrict__ scores,
                 long long ld, long long col0, float* __restrict__ maps_out,
                 const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned r_off, unsigned xbuf_off,
-                unsigned nyq_off_lds, unsigned* __restrict__ team_sync) {
+                unsigned nyq_off_lds, unsigned* __restrict__ team_sync, unsigned char* __restrict__ ws,
+                size_t slot_bytes) {
   using GH = typename C::GH;
   using GW = typename C::GW;
   const int nq = g.nq, ng = g.ng;
@@ -273,6 +282,7 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   unsigned char* lds = dyn_lds();
   float* red = reinterpret_cast<float*>(lds);
   cf* R = reinterpret_cast<cf*>(lds + r_off);
+  if constexpr (BIG) R = reinterpret_cast<cf*>(ws + static_cast<size_t>(blockIdx.x) * slot_bytes);
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
   cf* nyq = reinterpret_cast<cf*>(lds + nyq_off_lds);  // [0, NH): gallery column nw/2, [NH, 2NH): query's
   const int tid = static_cast<int>(threadIdx.x);
@@ -576,19 +586,33 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
 struct PrepFftLds {
   size_t x0_off, f_off, xbuf_off, zbuf_off, sat2_off, total;  // sat2_off = 0: the two tables do not fit together
   int f_stride;
+  size_t slot_bytes;  // big mode: bytes of one workgroup's workspace slot (x0_off / f_off / sat2_off index it)
 };
 template <class C>
 PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
   const int h = is_query ? g.th : g.ih, w = is_query ? g.tw : g.iw;
   PrepFftLds l;
-  l.x0_off = 64;
-  l.f_off = align_up(l.x0_off + sizeof(float) * h * w, 16);
   l.f_stride = C::NW / 2 + 1;
   const size_t f_bytes = sizeof(cf) * static_cast<size_t>(2 * ((h + 1) / 2)) * l.f_stride;
+  const size_t sat_bytes = align_up(sizeof(double) * (h + 1) * (w + 1), 16);
+  if (g.big) {
+    // LDS: reduction scratch + exchange buffers; slot: centred map | table 1 (later the row-pass output) | table 2
+    l.xbuf_off = 64;
+    l.zbuf_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads), 16);
+    l.total = l.zbuf_off + sizeof(cf) * (kThreads / C::TGW) * C::NW;
+    l.x0_off = 0;
+    l.f_off = align_up(sizeof(float) * h * w, 256);
+    const size_t first = f_bytes > sat_bytes ? f_bytes : sat_bytes;
+    l.sat2_off = align_up(l.f_off + first, 256);
+    l.slot_bytes = align_up(l.sat2_off + (is_query ? 0 : sat_bytes), 256);
+    return l;
+  }
+  l.slot_bytes = 0;
+  l.x0_off = 64;
+  l.f_off = align_up(l.x0_off + sizeof(float) * h * w, 16);
   l.xbuf_off = align_up(l.f_off + f_bytes, 16);
   l.zbuf_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads), 16);
   const size_t fft_total = l.zbuf_off + sizeof(cf) * (kThreads / C::TGW) * C::NW;
-  const size_t sat_bytes = align_up(sizeof(double) * (h + 1) * (w + 1), 16);
   size_t sat_total = is_query ? 0 : l.f_off + sat_bytes;
   l.sat2_off = 0;
   if (!is_query && l.f_off + 2 * sat_bytes <= static_cast<size_t>(kLdsLimit)) {  // single-sweep 1/sigma
@@ -600,7 +624,7 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
 }
 
 struct PairFftLds {
-  size_t r_off, xbuf_off, nyq_off, total;
+  size_t r_off, xbuf_off, nyq_off, total, slot_bytes;
 };
 // rows kept by the column pass: the tuned variant covers RR_A row rounds, the general one the whole grid
 template <class C>
@@ -610,7 +634,9 @@ template <class C>
 PairFftLds pair_fft_lds(const NccGeom& g) {
   PairFftLds l;
   l.r_off = 64;
-  l.xbuf_off = align_up(l.r_off + sizeof(cf) * static_cast<size_t>(C::COLS) * g.r_stride, 16);
+  const size_t r_bytes = sizeof(cf) * static_cast<size_t>(C::COLS) * g.r_stride;
+  l.slot_bytes = g.big ? align_up(r_bytes, 256) : 0;  // big mode: the image lives in a workspace slot
+  l.xbuf_off = align_up(l.r_off + (g.big ? 0 : r_bytes), 16);
   l.nyq_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(C::NT), 16);
   l.total = l.nyq_off + sizeof(cf) * (2 * C::NH + C::NH + C::NW);  // Nyquist columns + inverse twiddle tables
   return l;
@@ -624,36 +650,61 @@ struct FftEntry {
   int spec_per_chan;
   size_t (*prep_lds_total)(const NccGeom&, bool);
   size_t (*pair_lds_total)(const NccGeom&);
-  int (*prep)(const NccGeom&, bool, const void*, int64_t, void*, const cf*, const cf*, hipStream_t);
+  int (*prep)(const NccGeom&, bool, const void*, int64_t, void*, const cf*, const cf*, const FftWorkspace&, hipStream_t);
   int (*pair)(const NccGeom&, bool, const void*, int64_t, const void*, int64_t, float*, int64_t, int64_t, int, float*,
-              const cf*, const cf*, unsigned*, hipStream_t);
+              const cf*, const cf*, unsigned*, const FftWorkspace&, hipStream_t);
+  size_t (*prep_slot_bytes)(const NccGeom&, bool);
+  size_t (*pair_slot_bytes)(const NccGeom&);
+  bool big_only;  // grid whose working set never fits LDS: always the workspace ("big") kernels
 };
 
 template <class C>
 size_t prep_lds_total_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q).total; }
 template <class C>
 size_t pair_lds_total_t(const NccGeom& g) { return pair_fft_lds<C>(g).total; }
-
 template <class C>
-int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h, const cf* tw_w,
-           hipStream_t stream) {
+size_t prep_slot_bytes_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q).slot_bytes; }
+template <class C>
+size_t pair_slot_bytes_t(const NccGeom& g) { return pair_fft_lds<C>(g).slot_bytes; }
+
+template <class C, bool BIG>
+int prep_launch(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
+                const cf* tw_w, const FftWorkspace& ws, hipStream_t stream) {
   const PrepFftLds l = prep_fft_lds<C>(g, is_query);
   const size_t item_bytes = is_query ? prepared_query_item_bytes(g, SPR_NCC_FFT) : prepared_gallery_item_bytes(g, SPR_NCC_FFT);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kLdsLimit);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads),
-                     l.total, stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes, tw_h,
-                     tw_w, static_cast<unsigned>(l.x0_off), static_cast<unsigned>(l.f_off),
-                     static_cast<unsigned>(l.xbuf_off), static_cast<unsigned>(l.zbuf_off),
-                     static_cast<unsigned>(l.sat2_off), l.f_stride);
-  return check_launch("prep_fft_kernel");
+  // big mode: one workspace slot per workgroup of a launch, so the items go in batches the workspace can hold
+  int64_t batch = n;
+  if (BIG) {
+    const size_t per_item = l.slot_bytes * static_cast<size_t>(g.channels);
+    if (!ws.base || ws.bytes < per_item) { set_error("prep_fft_kernel: workspace too small for one item"); return SPR_ERR_WORKSPACE; }
+    batch = static_cast<int64_t>(ws.bytes / per_item);
+  }
+  const int raw_h = is_query ? g.q_h : g.g_h, raw_w = is_query ? g.q_w : g.g_w;
+  const size_t elem = g.dtype == SPR_F32 ? 4 : 2;
+  const size_t raw_item_bytes = static_cast<size_t>(g.channels) * raw_h * raw_w * elem;
+  for (int64_t first = 0; first < n; first += batch) {
+    const int64_t m = n - first < batch ? n - first : batch;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C, BIG>), dim3(g.channels, static_cast<unsigned>(m)), dim3(kThreads),
+                       l.total, stream, g, is_query ? 1 : 0,
+                       static_cast<const void*>(static_cast<const unsigned char*>(maps) + first * raw_item_bytes),
+                       static_cast<unsigned char*>(prepared) + first * item_bytes, item_bytes, tw_h,
+                       tw_w, static_cast<unsigned>(l.x0_off), static_cast<unsigned>(l.f_off),
+                       static_cast<unsigned>(l.xbuf_off), static_cast<unsigned>(l.zbuf_off),
+                       static_cast<unsigned>(l.sat2_off), l.f_stride, static_cast<unsigned char*>(ws.base), l.slot_bytes);
+    const int rc = check_launch("prep_fft_kernel");
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
+}
+template <class C>
+int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h, const cf* tw_w,
+           const FftWorkspace& ws, hipStream_t stream) {
+  return g.big ? prep_launch<C, true>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream)
+               : prep_launch<C, false>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
 }
 
-// Team mode is opt-in (SPR_NCC_TEAM=1; SPR_NCC_TEAM_POLLS / SPR_NCC_TEAM_EVERY tune the soft barrier).
-// Measured at Q=100 x G=1500 on conv3_3 maps: L2 hit rate 57 % -> 83 %, memory-side traffic 21.4 -> 8.6 MB per
-// pair, but 4 % SLOWER (237 k against 248 k pairs/s): the kernel is bound by LDS/VALU latency at two waves per
-// SIMD, not by memory, and every barrier waits for the slowest of 64 workgroups.  The tile schedule stays
-// the default; the team schedule is the one to use when HBM bandwidth is shared with other work.
 constexpr int kTeamCounters = 8 * 32;  // one 128-byte line per team
 
 inline int env_int(const char* name, int fallback) {
@@ -661,27 +712,33 @@ inline int env_int(const char* name, int fallback) {
   return v && *v ? std::atoi(v) : fallback;
 }
 
-template <class C, int RR, int KW, int PF, int RK>
+template <class C, int RR, int KW, int PF, int RK, bool BIG>
 int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
                 int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, unsigned* team_sync,
-                hipStream_t stream) {
+                const FftWorkspace& ws, hipStream_t stream) {
   const PairFftLds l = pair_fft_lds<C>(g);
   const int64_t tiles = static_cast<int64_t>(ceil_div(static_cast<int>(nq), kTileQ)) * ceil_div(static_cast<int>(ng), kTileG);
   PairArgs a{};
   a.channels = g.channels; a.nq = static_cast<int>(nq); a.ng = static_cast<int>(ng);
   a.ih = g.ih; a.iw = g.iw; a.r_rows = g.r_rows; a.r_stride = g.r_stride; a.rounds_r = g.rounds_r;
   a.inv_per_chan = g.inv_per_chan; a.accumulate = accumulate;
-  const void* kernel = reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK>);
+  const void* kernel = reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK, BIG>);
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
   unsigned grid = static_cast<unsigned>(tiles * kTileQ * kTileG);
   // ---- team mode: a persistent grid that exactly fills the device, 8 teams of co-resident workgroups ----
   int per_cu = 0, cus = 0, dev = 0;
-  if (team_sync && !maps_out && hipGetDevice(&dev) == hipSuccess &&
+  if (BIG && !team_sync) { set_error("pair_fft_kernel: big mode needs the plan's team counters"); return SPR_ERR_ARG; }
+  if (team_sync && (BIG || !maps_out) && hipGetDevice(&dev) == hipSuccess &&
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_fft_kernel<C, RR, KW, PF, RK>, C::NT, l.total) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_fft_kernel<C, RR, KW, PF, RK, BIG>, C::NT, l.total) == hipSuccess &&
       per_cu > 0 && cus >= 8) {
-    const int team_size = cus / 8 * per_cu;
-    if (env_int("SPR_NCC_TEAM", 0) == 1) {
+    int team_size = cus / 8 * per_cu;
+    if (BIG) {  // one workspace slot per resident workgroup: the persistent grid is the only launch form
+      const size_t slots = ws.base ? ws.bytes / l.slot_bytes : 0;
+      if (slots < 8) { set_error("pair_fft_kernel: workspace too small"); return SPR_ERR_WORKSPACE; }
+      if (static_cast<size_t>(team_size) * 8 > slots) team_size = static_cast<int>(slots / 8);
+    }
+    if (BIG || env_int("SPR_NCC_TEAM", 0) == 1) {
       const int strips = ceil_div(static_cast<int>(nq), 16);
       a.team_size = team_size;
       a.strips = strips;
@@ -690,8 +747,8 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
       a.epochs_full = static_cast<int>((static_cast<int64_t>(a.strip_q) * ng + team_size - 1) / team_size);
       const int q_last = static_cast<int>(nq) - (a.strips - 1) * a.strip_q;
       a.epochs_total = (a.strips - 1) * a.epochs_full + static_cast<int>((static_cast<int64_t>(q_last) * ng + team_size - 1) / team_size);
-      a.sync_polls = env_int("SPR_NCC_TEAM_POLLS", 256);
-      a.sync_every = env_int("SPR_NCC_TEAM_EVERY", 32);
+      a.sync_polls = BIG ? 0 : env_int("SPR_NCC_TEAM_POLLS", 256);
+      a.sync_every = BIG ? 0 : env_int("SPR_NCC_TEAM_EVERY", 32);
       if (a.sync_every < 0) a.sync_every = 0;
       grid = 8u * static_cast<unsigned>(team_size);
       if (hipMemsetAsync(team_sync, 0, sizeof(unsigned) * kTeamCounters, stream) != hipSuccess) {
@@ -700,35 +757,46 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
       }
     }
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK>), dim3(grid),
+  if (BIG && a.team_size == 0) { set_error("pair_fft_kernel: could not size the persistent grid"); return SPR_ERR_HIP; }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK, BIG>), dim3(grid),
                      dim3(C::NT), l.total, stream, a, static_cast<const unsigned char*>(pq),
                      prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
                      prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores,
                      static_cast<long long>(ld), static_cast<long long>(col0), maps_out, tw_h, tw_w,
                      static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off),
-                     static_cast<unsigned>(l.nyq_off), team_sync);
+                     static_cast<unsigned>(l.nyq_off), team_sync, static_cast<unsigned char*>(ws.base), l.slot_bytes);
   (void)kernel;
   return check_launch("pair_fft_kernel");
 }
 
 // tuned variant: KW_A x RR_A with PFA prefetch buffers; general variant: everything kept, one buffer
+template <class C, int PFA, bool BIG>
+int pair_tb(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
+            unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
+  if (tuned)
+    return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>(), BIG>(g, pq, nq, pg, ng, scores, ld, col0, accumulate,
+                                                                     maps_out, tw_h, tw_w, team_sync, ws, stream);
+  return pair_launch<C, C::RR_B, C::KW_B, 1, 0, BIG>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h,
+                                                     tw_w, team_sync, ws, stream);
+}
 template <class C, int PFA>
 int pair_t(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
-           unsigned* team_sync, hipStream_t stream) {
-  if (tuned)
-    return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>()>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out,
-                                                                tw_h, tw_w, team_sync, stream);
-  return pair_launch<C, C::RR_B, C::KW_B, 1, 0>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
-                                                team_sync, stream);
+           unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
+  return g.big ? pair_tb<C, PFA, true>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                       team_sync, ws, stream)
+               : pair_tb<C, PFA, false>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                        team_sync, ws, stream);
 }
 
-template <class C, int PFA>
+template <class C, int PFA, bool BIG_ONLY = false>
 constexpr FftEntry entry() {
   return FftEntry{C::NH,   C::NW,   C::EH,   C::TGH,  C::EW,   C::TGW, C::NT, C::GW::SPL,
                   C::KW_A, C::RR_A, C::KW_B, C::RR_B, rk_tuned<C>(),
                   (C::NH & (C::NH - 1)) == 0 && (C::NW & (C::NW - 1)) == 0,
-                  C::kSpecPerChan, prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C, PFA>};
+                  C::kSpecPerChan, prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C, PFA>,
+                  prep_slot_bytes_t<C>, pair_slot_bytes_t<C>, BIG_ONLY};
 }
 
 // (E, TG) factorisations: 256 = 16*16, 192 = 12*16, 128 = 16*8, 96 = 12*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
@@ -749,6 +817,8 @@ const FftEntry kEntries[] = {
     entry<Cfg<16, 8, 16, 8, 256, 4, 1>, 1>(),     // 128 x 128
     entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),    // 192 x 96: conv3_3 of a 512x256 print; two workgroups per CU
     entry<Cfg<16, 16, 16, 8, 512, 4, 1>, 2>(),    // 256 x 128: 8 waves per workgroup, one workgroup per CU
+    entry<Cfg<24, 16, 12, 16, 512, 11, 4>, 1, true>(),  // 384 x 192: maps up to 256 x 128 (conv3_3 of a 1024x512 print,
+                                                        // conv2_2 of 512x256); working set in the global workspace
 };
 
 const FftEntry* find_entry(int nh, int nw) {
@@ -763,7 +833,8 @@ inline int fft_need(int img, int tpl) {
   return a > b ? a : b;
 }
 
-bool fill_geometry(NccGeom& g, const FftEntry& e) {
+bool fill_geometry(NccGeom& g, const FftEntry& e, bool big) {
+  g.big = big ? 1 : 0;
   g.nh = e.nh; g.nw = e.nw; g.eh = e.eh; g.tgh = e.tgh; g.ew = e.ew; g.tgw = e.tgw; g.nt = e.nt;
   const int cpr = e.nt / e.tgh, ppr = e.nt / e.tgw;
   g.rounds_c = ceil_div(e.nw / 2, cpr);
@@ -779,7 +850,8 @@ bool fill_geometry(NccGeom& g, const FftEntry& e) {
   g.nv = (e.spl_w * g.keep_w * 2 + 3) / 4 * 4;
   g.spec_per_chan = e.spec_per_chan;
   g.inv_per_chan = g.rounds_r * g.nv * e.nt;
-  if (g.ih * g.iw > kMaxPixPerThread * kThreads || g.th * g.tw > kMaxPixPerThread * kThreads) return false;
+  // (the two-sweep 1/sigma path of the LDS mode keeps per-lane register arrays; big mode is always single-sweep)
+  if (!big && (g.ih * g.iw > kMaxPixPerThread * kThreads || g.th * g.tw > kMaxPixPerThread * kThreads)) return false;
   if (e.prep_lds_total(g, true) > static_cast<size_t>(kLdsLimit)) return false;
   if (e.prep_lds_total(g, false) > static_cast<size_t>(kLdsLimit)) return false;
   if (e.pair_lds_total(g) > static_cast<size_t>(kLdsLimit)) return false;
@@ -795,35 +867,51 @@ bool fft_geometry(NccGeom& g, bool pow2_only) {
   const int min_h = need_h > g.th ? need_h : g.th, min_w = need_w > g.tw ? need_w : g.tw;
   const FftEntry* best = nullptr;
   NccGeom best_g = g;
-  for (const FftEntry& e : kEntries) {
-    if (e.nh < min_h || e.nw < min_w) continue;
-    if (pow2_only && !e.pow2) continue;
-    if (best && static_cast<long long>(e.nh) * e.nw >= static_cast<long long>(best->nh) * best->nw) continue;
-    NccGeom trial = g;
-    if (!fill_geometry(trial, e)) continue;
-    best = &e;
-    best_g = trial;
+  // smallest grid whose working set fits LDS; failing that, smallest grid with the working set in the global
+  // workspace ("big" mode: any size the largest grid covers).  SPR_NCC_FORCE_BIG=1 skips the first pass (tests).
+  const bool force_big = env_int("SPR_NCC_FORCE_BIG", 0) == 1;
+  for (int pass = force_big ? 1 : 0; pass < 2 && !best; ++pass) {
+    for (const FftEntry& e : kEntries) {
+      if (e.nh < min_h || e.nw < min_w) continue;
+      if (pow2_only && !e.pow2) continue;
+      if (pass == 0 && e.big_only) continue;
+      if (best && static_cast<long long>(e.nh) * e.nw >= static_cast<long long>(best->nh) * best->nw) continue;
+      NccGeom trial = g;
+      if (!fill_geometry(trial, e, pass == 1)) continue;
+      best = &e;
+      best_g = trial;
+    }
   }
   if (!best) return false;
   g = best_g;
   return true;
 }
 
+size_t fft_workspace_bytes(const NccGeom& g) {
+  if (!g.big) return 0;
+  const FftEntry* e = find_entry(g.nh, g.nw);
+  if (!e) return 0;
+  const size_t prep_q = e->prep_slot_bytes(g, true), prep_g = e->prep_slot_bytes(g, false);
+  const size_t prep = (prep_q > prep_g ? prep_q : prep_g) * static_cast<size_t>(g.channels) * 2;  // two items per launch
+  const size_t pair = e->pair_slot_bytes(g) * 512;  // a persistent grid of up to 512 workgroups
+  return prep > pair ? prep : pair;
+}
+
 int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
-                    const cf* tw_w, hipStream_t stream) {
+                    const cf* tw_w, const FftWorkspace& ws, hipStream_t stream) {
   if (n == 0) return SPR_OK;
   const FftEntry* e = find_entry(g.nh, g.nw);
   if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
-  return e->prep(g, is_query, maps, n, prepared, tw_h, tw_w, stream);
+  return e->prep(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
 }
 
 int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
-                    unsigned* team_sync, hipStream_t stream) {
+                    unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
   if (nq == 0 || ng == 0) return SPR_OK;
   const FftEntry* e = find_entry(g.nh, g.nw);
   if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
-  return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, team_sync, stream);
+  return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, team_sync, ws, stream);
 }
 
 }  // namespace spr

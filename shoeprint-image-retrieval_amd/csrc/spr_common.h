@@ -40,6 +40,7 @@ struct NccGeom {
   int nh, nw;          // FFT grid (rows, cols); nh = eh*tgh, nw = ew*tgw
   int nt;              // work-items per workgroup of the pair kernel (prepared layouts are tiled by it)
   int eh, tgh, ew, tgw;
+  int big;             // 1: working set in the plan's global workspace instead of LDS (maps too large for LDS)
   int tight;           // 1: ih <= nh/2 and iw <= nw/2 (the pruned kernel variant), 0: general variant
   int rounds_c;        // column-pass rounds of (kThreads/tgh) columns covering nw/2 columns
   int r_rows;          // rows of the intermediate LDS image kept after the column pass (ih rounded up to 8)
@@ -64,11 +65,17 @@ int launch_prep_direct(const NccGeom& g, bool is_query, const void* maps, int64_
                        hipStream_t stream);
 int launch_pair_direct(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                        int64_t ld, int64_t col0, int accumulate, float* maps_out, hipStream_t stream);
+struct FftWorkspace {  // the plan's scratch for "big" FFT geometries (null / 0 otherwise)
+  void* base;
+  size_t bytes;
+};
+size_t fft_workspace_bytes(const NccGeom& g);  // what a plan with this geometry must allocate (0: none)
 int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
-                    const cf* tw_w, hipStream_t stream);
+                    const cf* tw_w, const FftWorkspace& ws, hipStream_t stream);
 int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
-                    unsigned* team_sync, hipStream_t stream);  // team_sync: 8 x 32 counters, or null (tile mode only)
+                    unsigned* team_sync, const FftWorkspace& ws,
+                    hipStream_t stream);  // team_sync: 8 x 32 counters, or null (tile mode only)
 bool fft_geometry(NccGeom& g, bool pow2_only);  // fills the FFT fields; false if no instantiated kernel fits
 bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps do not fit LDS
 

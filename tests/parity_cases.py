@@ -158,6 +158,31 @@ def check_config5_multi_layer_fp16(scorer, channels):
     np.testing.assert_allclose(got, np.mean(refs, axis=0), atol=TIGHT, rtol=0)
 
 
+def check_big_mode(make_scorer, monkeypatch, full):
+    """Maps beyond LDS: the prep / pair kernels keep their working set in the plan's global workspace.
+    (1) forced on shapes that also fit LDS (SPR_NCC_FORCE_BIG=1) the scores are bit-identical to the LDS mode;
+    (2) a conv3_3-of-an-800x400-print sized pair (200x100 maps -> 384x192 grid), only possible in this mode,
+    against the oracle."""
+    for case in ((2, 32, 16, 32, 16), (2, 40, 40, 40, 40), (2, 30, 17, 33, 15), (1, 64, 32, 64, 32)):
+        c, qh, qw, gh, gw = case
+        q = [synth.gallery_features(61, 100 + i, c, qh, qw) for i in range(3)]
+        g = [synth.gallery_features(61, i, c, gh, gw) for i in range(4)]
+        monkeypatch.delenv("SPR_NCC_FORCE_BIG", raising=False)
+        lds = make_scorer().score_matrix(q, g)
+        monkeypatch.setenv("SPR_NCC_FORCE_BIG", "1")
+        big = make_scorer().score_matrix(q, g)  # a fresh scorer: the mode is fixed when the plan is created
+        monkeypatch.delenv("SPR_NCC_FORCE_BIG")
+        np.testing.assert_array_equal(big, lds)
+    c, h, w = (4, 200, 100) if full else (1, 200, 100)
+    sc = make_scorer()
+    assert sc.plan(c, (h, w), (h, w)).fft_size == (384, 192)
+    q = [synth.query_features(62, i, i, c, h, w) for i in range(2)]
+    g = [synth.gallery_features(62, i, c, h, w) for i in range(2 if not full else 3)]
+    got = sc.score_matrix(q, g)
+    ref = oracle.similarity_matrix(q, g, precise=True)
+    np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
+
+
 def check_rank_kernel(scorer):
     rng = np.random.default_rng(5)
     for nq, ng in [(1, 1), (3, 7), (5, 300), (2, 1500)]:

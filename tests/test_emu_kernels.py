@@ -52,6 +52,10 @@ def test_emu_team_schedule(monkeypatch):
     pc.check_team_mode(emu_scorer("fft"), monkeypatch)
 
 
+def test_emu_big_mode(monkeypatch):
+    pc.check_big_mode(lambda: emu_scorer("fft"), monkeypatch, full=False)
+
+
 def test_emu_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 

@@ -79,6 +79,12 @@ def test_config5_multi_layer_fp16(fft_scorer):
     pc.check_config5_multi_layer_fp16(fft_scorer, channels=(256, 512, 512))
 
 
+def test_big_mode(lib, monkeypatch):
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+
+    pc.check_big_mode(lambda: NccScorer(method="fft", library=lib), monkeypatch, full=True)
+
+
 def test_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 
@@ -234,6 +240,11 @@ def test_run_driver_on_an_image_directory(tmp_path, capsys):
     got = run_mi355x.main(str(toml))
     out = capsys.readouterr().out
     assert "2 clusters of image sizes found." in out and "rank-1:" in out
+    # second run with a gallery feature cache: first fills it, then reads it; ranks unchanged
+    toml.write_text(toml.read_text() + f'[mi355x]\ngallery_cache = "{tmp_path}/cache"\n')
+    assert run_mi355x.main(str(toml)) == got
+    assert run_mi355x.main(str(toml)) == got
+    assert "Gallery features from" in capsys.readouterr().out
     want = []
     for queries, gallery, matches, block in Dataloader(cfg):
         params = synth.vgg16_parameters(1234, vgg_oracle.conv_shapes(block))
