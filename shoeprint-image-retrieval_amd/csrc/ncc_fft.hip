@@ -53,6 +53,14 @@ struct Cfg {
   static constexpr int xbuf_elems(int threads) {
     return GH::block_elems(threads) > GW::block_elems(threads) ? GH::block_elems(threads) : GW::block_elems(threads);
   }
+  // prep kernel: a row group's buffer also stages the NW outputs of its transform for the two-row split
+  // (group stride == TGW (mod 16), as in GroupFft)
+  static constexpr int kRowRaw = GW::kGroupElems > NW ? GW::kGroupElems : NW;
+  static constexpr int kRowGroupElems = kRowRaw + ((TGW % 16) - (kRowRaw % 16) + 16) % 16;
+  static constexpr int prep_xbuf_elems(int threads) {
+    return GH::block_elems(threads) > (threads / TGW) * kRowGroupElems ? GH::block_elems(threads)
+                                                                      : (threads / TGW) * kRowGroupElems;
+  }
   // Position of spectrum element (column j < COLS, k1) in a channel's prepared data: the pair kernel's
   // lane (group j % CPR, lane-in-group k1 % TGH) loads registers (2mm, 2mm+1), m = k1 / TGH, of column
   // round j / CPR with one 16-byte access.
@@ -75,8 +83,10 @@ inline int rt_stride(int r_rows) { return r_rows + ((8 - r_rows % 32) + 32) % 32
 // BIG: maps too large for LDS.  The centred map, the two float64 tables and the row-pass output then live in a
 // per-workgroup slot of a global workspace (x0_off / f_off / sat2_off are offsets into the slot); only the
 // exchange buffers stay in LDS.  Same code, same arithmetic - the slot is L2-resident scratch.
-template <class C, bool BIG>
-__global__ void __launch_bounds__(kThreads)
+// PT = work-items of this kernel's workgroups: LDS allows one workgroup per CU on the larger grids, so those run
+// 8 waves (two per SIMD) to overlap the LDS round trips of the transform rounds; small grids keep 4.
+template <class C, bool BIG, int PT>
+__global__ void __launch_bounds__(PT)
 prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                 size_t item_bytes, const cf* __restrict__ tw_h, const cf* __restrict__ tw_w, unsigned x0_off,
                 unsigned f_off, unsigned xbuf_off, unsigned zbuf_off, unsigned sat2_off, int f_stride,
@@ -91,7 +101,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   double* sat = reinterpret_cast<double*>(big + f_off);  // dead before F is written
   cf* F = reinterpret_cast<cf*>(big + f_off);
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
-  cf* zbuf = reinterpret_cast<cf*>(lds + zbuf_off);
+  (void)zbuf_off;
   const int tid = static_cast<int>(threadIdx.x);
   const int c = static_cast<int>(blockIdx.x);
   const size_t item = blockIdx.y;
@@ -106,7 +116,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     // channel's slot first; the workgroup barriers below order these stores before the values written later
     float4* inv4 = reinterpret_cast<float4*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
                    static_cast<size_t>(c) * (g.inv_per_chan / 4);
-    for (int i = tid; i < g.inv_per_chan / 4; i += kThreads) inv4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = tid; i < g.inv_per_chan / 4; i += PT) inv4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
   }
   load_centred(maps, (item * g.channels + c) * static_cast<size_t>(raw_h) * raw_w, raw_w, g.crop, h, w, g.dtype, x0,
                red);
@@ -139,10 +149,10 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     const int giw = tid / C::TGW, t = tid - giw * C::TGW;
     RegTwiddles<C::EW> twr;
     load_twiddles<C::EW, C::TGW, -1>(twr, tw_w, t);
-    cf* gbuf = xbuf + giw * GW::kGroupElems;
-    cf* zb = zbuf + giw * C::NW;
+    cf* gbuf = xbuf + giw * C::kRowGroupElems;
+    cf* zb = gbuf;  // the group's exchange buffer doubles as the staging row of the two-row split (>= NW elements)
     const int pairs = (h + 1) / 2;
-    constexpr int kPairsPerRound = kThreads / C::TGW;
+    constexpr int kPairsPerRound = PT / C::TGW;
     const int rounds = ceil_div(pairs, kPairsPerRound);
     for (int rr = 0; rr < rounds; ++rr) {
       const int pr = rr * kPairsPerRound + giw;
@@ -156,6 +166,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
         x[m].y = (in && rb < h) ? x0[rb * w + n2] * scale : 0.0f;
       }
       group_fft<C::EW, C::TGW, -1>(x, y, t, twr, gbuf);
+      wave_sync();  // every lane of the group has read its exchange values before the buffer is reused
       // publish Z[k] for the group, then split the two real rows:  Xa = (Z[k] + conj Z[-k])/2,
       // Xb = (Z[k] - conj Z[-k])/(2i)
 #pragma unroll
@@ -185,12 +196,12 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     cf* gbuf = xbuf + gi * GH::kGroupElems;
     const int rows_f = 2 * ((h + 1) / 2);
     const int cy = g.th / 2, cx = g.tw / 2;
-    constexpr int kColsPerRound = kThreads / C::TGH;
-    const int rounds = ceil_div(C::COLS, kColsPerRound);
-    for (int rc = 0; rc <= rounds; ++rc) {
-      const bool nyq = rc == rounds;
-      const int j = nyq ? C::COLS : rc * kColsPerRound + gi;
-      const bool active = nyq ? gi == 0 : j < C::COLS;
+    constexpr int kColsPerRound = PT / C::TGH;
+    constexpr int kRounds = (C::COLS + 1 + kColsPerRound - 1) / kColsPerRound;  // COLS columns + column nw/2
+    for (int rc = 0; rc < kRounds; ++rc) {
+      const int j = rc * kColsPerRound + gi;
+      const bool nyq = j == C::COLS;
+      const bool active = j <= C::COLS;
       cf x[C::EH], y[GH::SPL][C::TGH];
 #pragma unroll
       for (int m = 0; m < C::EH; ++m) {
@@ -267,7 +278,9 @@ struct PairArgs {
 // stage-2 outputs beyond it are dead code and the stores need no per-row test; 0 = runtime r_rows)
 // BIG: the intermediate image does not fit LDS; it lives in this workgroup's slot of a global workspace (the
 // launch is then always the persistent team grid, one slot per resident workgroup).
-template <class C, int RR, int KW, int PF, int RK, bool BIG>
+// TEAM: the persistent-grid schedule is its own instantiation, so the default one-pair-per-workgroup kernel
+// carries none of its scalar state (measured: 1.8 % when both lived in one kernel).  BIG implies TEAM.
+template <class C, int RR, int KW, int PF, int RK, bool BIG, bool TEAM>
 __global__ void __launch_bounds__(C::NT, BIG ? 1 : ((C::NT == 64 && RK > 0) ? 4 : 2))
 pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_bytes,
                 const unsigned char* __restrict__ pg, size_t g_item_bytes, float* __restrict__ scores,
@@ -361,18 +374,19 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   // epoch being team_size consecutive pairs of a query strip in gallery-major order (so ~strip_q queries x
   // team_size/strip_q gallery items: every spectrum line has many readers on this L2), and the members
   // start each pair together (soft barrier) so that those readers are close in time as well.
+  static_assert(TEAM || !BIG, "the workspace mode runs on the persistent grid");
   const int team = static_cast<int>(blockIdx.x) & 7, member = static_cast<int>(blockIdx.x) >> 3;
   unsigned* sync_ctr = team_sync + team * 32;
   unsigned sync_target = 0;
-  const int syncs_per_pair = g.sync_every > 0 ? ceil_div(g.channels, g.sync_every) : 1;
-  int epoch = 0, epoch_end = 1;
-  if (g.team_size > 0) {
+  int epoch = 0, epoch_end = 1, syncs_per_pair = 1;
+  if constexpr (TEAM) {
+    syncs_per_pair = g.sync_every > 0 ? ceil_div(g.channels, g.sync_every) : 1;
     epoch = static_cast<int>(static_cast<long long>(g.epochs_total) * team / 8);
     epoch_end = static_cast<int>(static_cast<long long>(g.epochs_total) * (team + 1) / 8);
   }
   for (; epoch < epoch_end; ++epoch) {
   int qi, gi_item;
-  if (g.team_size > 0) {
+  if constexpr (TEAM) {
     int strip = epoch / g.epochs_full;
     strip = strip < g.strips ? strip : g.strips - 1;
     const int q0 = strip * g.strip_q;
@@ -423,7 +437,7 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   __syncthreads();
 
   for (int c = 0; c < g.channels; ++c) {
-    if (g.sync_every > 0 && c > 0 && c % g.sync_every == 0) {  // team mode only (sync_every is 0 otherwise)
+    if (TEAM && g.sync_every > 0 && c > 0 && c % g.sync_every == 0) {
       sync_target += g.team_size;
       if (tid == 0) {  // the other waves run on to the next workgroup barrier
         team_arrive(sync_ctr, 1u);
@@ -589,7 +603,7 @@ struct PrepFftLds {
   size_t slot_bytes;  // big mode: bytes of one workgroup's workspace slot (x0_off / f_off / sat2_off index it)
 };
 template <class C>
-PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
+PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query, int pt) {
   const int h = is_query ? g.th : g.ih, w = is_query ? g.tw : g.iw;
   PrepFftLds l;
   l.f_stride = C::NW / 2 + 1;
@@ -598,8 +612,8 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
   if (g.big) {
     // LDS: reduction scratch + exchange buffers; slot: centred map | table 1 (later the row-pass output) | table 2
     l.xbuf_off = 64;
-    l.zbuf_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads), 16);
-    l.total = l.zbuf_off + sizeof(cf) * (kThreads / C::TGW) * C::NW;
+    l.zbuf_off = l.xbuf_off;  // (the two-row split stages through the exchange buffer)
+    l.total = l.xbuf_off + sizeof(cf) * C::prep_xbuf_elems(pt);
     l.x0_off = 0;
     l.f_off = align_up(sizeof(float) * h * w, 256);
     const size_t first = f_bytes > sat_bytes ? f_bytes : sat_bytes;
@@ -611,8 +625,8 @@ PrepFftLds prep_fft_lds(const NccGeom& g, bool is_query) {
   l.x0_off = 64;
   l.f_off = align_up(l.x0_off + sizeof(float) * h * w, 16);
   l.xbuf_off = align_up(l.f_off + f_bytes, 16);
-  l.zbuf_off = align_up(l.xbuf_off + sizeof(cf) * C::xbuf_elems(kThreads), 16);
-  const size_t fft_total = l.zbuf_off + sizeof(cf) * (kThreads / C::TGW) * C::NW;
+  l.zbuf_off = l.xbuf_off;
+  const size_t fft_total = l.xbuf_off + sizeof(cf) * C::prep_xbuf_elems(pt);
   size_t sat_total = is_query ? 0 : l.f_off + sat_bytes;
   l.sat2_off = 0;
   if (!is_query && l.f_off + 2 * sat_bytes <= static_cast<size_t>(kLdsLimit)) {  // single-sweep 1/sigma
@@ -658,22 +672,28 @@ struct FftEntry {
   bool big_only;  // grid whose working set never fits LDS: always the workspace ("big") kernels
 };
 
+// Work-items of the prep kernel: 8 waves where the grid gives them work and their exchange buffers fit
 template <class C>
-size_t prep_lds_total_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q).total; }
+int prep_threads(const NccGeom& g, bool q) {
+  if (C::NH * C::NW >= 128 * 64 && prep_fft_lds<C>(g, q, 512).total <= static_cast<size_t>(kLdsLimit)) return 512;
+  return kThreads;
+}
+template <class C>
+size_t prep_lds_total_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q, prep_threads<C>(g, q)).total; }
 template <class C>
 size_t pair_lds_total_t(const NccGeom& g) { return pair_fft_lds<C>(g).total; }
 template <class C>
-size_t prep_slot_bytes_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q).slot_bytes; }
+size_t prep_slot_bytes_t(const NccGeom& g, bool q) { return prep_fft_lds<C>(g, q, kThreads).slot_bytes; }
 template <class C>
 size_t pair_slot_bytes_t(const NccGeom& g) { return pair_fft_lds<C>(g).slot_bytes; }
 
-template <class C, bool BIG>
+template <class C, bool BIG, int PT>
 int prep_launch(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
                 const cf* tw_w, const FftWorkspace& ws, hipStream_t stream) {
-  const PrepFftLds l = prep_fft_lds<C>(g, is_query);
+  const PrepFftLds l = prep_fft_lds<C>(g, is_query, PT);
   const size_t item_bytes = is_query ? prepared_query_item_bytes(g, SPR_NCC_FFT) : prepared_gallery_item_bytes(g, SPR_NCC_FFT);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsLimit);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_fft_kernel<C, BIG, PT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
   // big mode: one workspace slot per workgroup of a launch, so the items go in batches the workspace can hold
   int64_t batch = n;
   if (BIG) {
@@ -686,7 +706,7 @@ int prep_launch(const NccGeom& g, bool is_query, const void* maps, int64_t n, vo
   const size_t raw_item_bytes = static_cast<size_t>(g.channels) * raw_h * raw_w * elem;
   for (int64_t first = 0; first < n; first += batch) {
     const int64_t m = n - first < batch ? n - first : batch;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C, BIG>), dim3(g.channels, static_cast<unsigned>(m)), dim3(kThreads),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_fft_kernel<C, BIG, PT>), dim3(g.channels, static_cast<unsigned>(m)), dim3(PT),
                        l.total, stream, g, is_query ? 1 : 0,
                        static_cast<const void*>(static_cast<const unsigned char*>(maps) + first * raw_item_bytes),
                        static_cast<unsigned char*>(prepared) + first * item_bytes, item_bytes, tw_h,
@@ -701,8 +721,10 @@ int prep_launch(const NccGeom& g, bool is_query, const void* maps, int64_t n, vo
 template <class C>
 int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h, const cf* tw_w,
            const FftWorkspace& ws, hipStream_t stream) {
-  return g.big ? prep_launch<C, true>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream)
-               : prep_launch<C, false>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
+  if (g.big) return prep_launch<C, true, kThreads>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
+  if (prep_threads<C>(g, is_query) == 512)
+    return prep_launch<C, false, 512>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
+  return prep_launch<C, false, kThreads>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
 }
 
 constexpr int kTeamCounters = 8 * 32;  // one 128-byte line per team
@@ -712,7 +734,7 @@ inline int env_int(const char* name, int fallback) {
   return v && *v ? std::atoi(v) : fallback;
 }
 
-template <class C, int RR, int KW, int PF, int RK, bool BIG>
+template <class C, int RR, int KW, int PF, int RK, bool BIG, bool TEAM>
 int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
                 int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w, unsigned* team_sync,
                 const FftWorkspace& ws, hipStream_t stream) {
@@ -722,15 +744,15 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
   a.channels = g.channels; a.nq = static_cast<int>(nq); a.ng = static_cast<int>(ng);
   a.ih = g.ih; a.iw = g.iw; a.r_rows = g.r_rows; a.r_stride = g.r_stride; a.rounds_r = g.rounds_r;
   a.inv_per_chan = g.inv_per_chan; a.accumulate = accumulate;
-  const void* kernel = reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK, BIG>);
+  const void* kernel = reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK, BIG, TEAM>);
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
   unsigned grid = static_cast<unsigned>(tiles * kTileQ * kTileG);
   // ---- team mode: a persistent grid that exactly fills the device, 8 teams of co-resident workgroups ----
   int per_cu = 0, cus = 0, dev = 0;
-  if (BIG && !team_sync) { set_error("pair_fft_kernel: big mode needs the plan's team counters"); return SPR_ERR_ARG; }
-  if (team_sync && (BIG || !maps_out) && hipGetDevice(&dev) == hipSuccess &&
+  if (TEAM && !team_sync) { set_error("pair_fft_kernel: the team schedule needs the plan's counters"); return SPR_ERR_ARG; }
+  if (TEAM && hipGetDevice(&dev) == hipSuccess &&
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_fft_kernel<C, RR, KW, PF, RK, BIG>, C::NT, l.total) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_fft_kernel<C, RR, KW, PF, RK, BIG, TEAM>, C::NT, l.total) == hipSuccess &&
       per_cu > 0 && cus >= 8) {
     int team_size = cus / 8 * per_cu;
     if (BIG) {  // one workspace slot per resident workgroup: the persistent grid is the only launch form
@@ -738,7 +760,7 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
       if (slots < 8) { set_error("pair_fft_kernel: workspace too small"); return SPR_ERR_WORKSPACE; }
       if (static_cast<size_t>(team_size) * 8 > slots) team_size = static_cast<int>(slots / 8);
     }
-    if (BIG || env_int("SPR_NCC_TEAM", 0) == 1) {
+    {
       const int strips = ceil_div(static_cast<int>(nq), 16);
       a.team_size = team_size;
       a.strips = strips;
@@ -757,8 +779,8 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
       }
     }
   }
-  if (BIG && a.team_size == 0) { set_error("pair_fft_kernel: could not size the persistent grid"); return SPR_ERR_HIP; }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK, BIG>), dim3(grid),
+  if (TEAM && a.team_size == 0) { set_error("pair_fft_kernel: could not size the persistent grid"); return SPR_ERR_HIP; }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK, BIG, TEAM>), dim3(grid),
                      dim3(C::NT), l.total, stream, a, static_cast<const unsigned char*>(pq),
                      prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
                      prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores,
@@ -770,24 +792,28 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
 }
 
 // tuned variant: KW_A x RR_A with PFA prefetch buffers; general variant: everything kept, one buffer
-template <class C, int PFA, bool BIG>
+template <class C, int PFA, bool BIG, bool TEAM>
 int pair_tb(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
             int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
             unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
   if (tuned)
-    return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>(), BIG>(g, pq, nq, pg, ng, scores, ld, col0, accumulate,
-                                                                     maps_out, tw_h, tw_w, team_sync, ws, stream);
-  return pair_launch<C, C::RR_B, C::KW_B, 1, 0, BIG>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h,
-                                                     tw_w, team_sync, ws, stream);
+    return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>(), BIG, TEAM>(g, pq, nq, pg, ng, scores, ld, col0, accumulate,
+                                                                           maps_out, tw_h, tw_w, team_sync, ws, stream);
+  return pair_launch<C, C::RR_B, C::KW_B, 1, 0, BIG, TEAM>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out,
+                                                           tw_h, tw_w, team_sync, ws, stream);
 }
 template <class C, int PFA>
 int pair_t(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
            unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
-  return g.big ? pair_tb<C, PFA, true>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
-                                       team_sync, ws, stream)
-               : pair_tb<C, PFA, false>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+  if (g.big)
+    return pair_tb<C, PFA, true, true>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                       team_sync, ws, stream);
+  if (team_sync && !maps_out && env_int("SPR_NCC_TEAM", 0) == 1)
+    return pair_tb<C, PFA, false, true>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
                                         team_sync, ws, stream);
+  return pair_tb<C, PFA, false, false>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
+                                       team_sync, ws, stream);
 }
 
 template <class C, int PFA, bool BIG_ONLY = false>

@@ -6,7 +6,10 @@
 
 namespace spr {
 
-constexpr int kMaxPixPerThread = 48;  // cropped maps of up to 48*256 = 12288 pixels
+constexpr int kMaxPixPerThread = 48;  // two-sweep 1/sigma path: cropped maps of up to 48 pixels per work-item
+
+// All helpers here run on whatever workgroup size the kernel was launched with (a multiple of 64).
+__device__ __forceinline__ int wg_size() { return static_cast<int>(blockDim.x); }
 
 // x0[y*w + x] = crop(map)[y][x] - mean(crop(map)), float32 arithmetic on a float64-accumulated mean.
 // Returns after a workgroup barrier.
@@ -15,10 +18,10 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
   const int tid = static_cast<int>(threadIdx.x);
   const int n = h * w;
   double s = 0.0;
-  // (y, x) of pixel i = tid + k*kThreads advance incrementally: one division per lane, not per pixel
-  const int dy = kThreads / w, dx = kThreads - dy * w;
+  // (y, x) of pixel i = tid + k*wg_size() advance incrementally: one division per lane, not per pixel
+  const int dy = wg_size() / w, dx = wg_size() - dy * w;
   int y = tid / w, x = tid - y * w;
-  for (int i = tid; i < n; i += kThreads) {
+  for (int i = tid; i < n; i += wg_size()) {
     const float v = load_feature(maps, chan_base + static_cast<size_t>(y + crop) * raw_w + (x + crop), dtype);
     x0[i] = v;
     s += static_cast<double>(v);
@@ -27,7 +30,7 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
   }
   const double total = block_sum(s, red);
   const float mean = static_cast<float>(total / static_cast<double>(n));
-  for (int i = tid; i < n; i += kThreads) x0[i] = x0[i] - mean;
+  for (int i = tid; i < n; i += wg_size()) x0[i] = x0[i] - mean;
   __syncthreads();
 }
 
@@ -35,7 +38,7 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
 __device__ __forceinline__ float template_scale(const float* x0, int n, double* red) {
   const int tid = static_cast<int>(threadIdx.x);
   double s = 0.0;
-  for (int i = tid; i < n; i += kThreads) {
+  for (int i = tid; i < n; i += wg_size()) {
     const float v = x0[i];
     const float sq = v * v;  // np.square keeps float32 (:67)
     s += static_cast<double>(sq);
@@ -52,8 +55,8 @@ __device__ __forceinline__ void build_sat(const float* __restrict__ x0, int h, i
   const int tid = static_cast<int>(threadIdx.x);
   const int stride = w + 1;
   constexpr int B = 8;
-  for (int x = tid; x <= w; x += kThreads) sat[x] = 0.0;
-  for (int y = tid; y < h; y += kThreads) {
+  for (int x = tid; x <= w; x += wg_size()) sat[x] = 0.0;
+  for (int y = tid; y < h; y += wg_size()) {
     double run = 0.0;
     double* row = sat + static_cast<size_t>(y + 1) * stride;
     const float* src = x0 + y * w;
@@ -75,7 +78,7 @@ __device__ __forceinline__ void build_sat(const float* __restrict__ x0, int h, i
     }
   }
   __syncthreads();
-  for (int x = tid; x <= w; x += kThreads) {
+  for (int x = tid; x <= w; x += wg_size()) {
     double run = 0.0;
     for (int yb = 1; yb <= h; yb += B) {
       double v[B];
@@ -110,8 +113,8 @@ __device__ __forceinline__ void build_sat_pair(const float* __restrict__ x0, int
   const int tid = static_cast<int>(threadIdx.x);
   const int stride = w + 1;
   constexpr int B = 8;
-  for (int x = tid; x <= w; x += kThreads) { sat1[x] = 0.0; sat2[x] = 0.0; }
-  for (int y = tid; y < h; y += kThreads) {
+  for (int x = tid; x <= w; x += wg_size()) { sat1[x] = 0.0; sat2[x] = 0.0; }
+  for (int y = tid; y < h; y += wg_size()) {
     double r1 = 0.0, r2 = 0.0;
     double* row1 = sat1 + static_cast<size_t>(y + 1) * stride;
     double* row2 = sat2 + static_cast<size_t>(y + 1) * stride;
@@ -132,7 +135,7 @@ __device__ __forceinline__ void build_sat_pair(const float* __restrict__ x0, int
   }
   __syncthreads();
   // column scans: lanes [0, w] take table 1, lanes [w+1, 2w+1] table 2
-  for (int j = tid; j < 2 * stride; j += kThreads) {
+  for (int j = tid; j < 2 * stride; j += wg_size()) {
     double* sat = j < stride ? sat1 : sat2;
     const int x = j < stride ? j : j - stride;
     double run = 0.0;
@@ -173,9 +176,9 @@ __device__ __forceinline__ void inv_sigma_map_fused(const float* x0, int h, int 
   build_sat_pair(x0, h, w, sat1, sat2);
   const double inv_n = 1.0 / (static_cast<double>(th) * static_cast<double>(tw));
   const int stride = w + 1;
-  const int dy = kThreads / w, dx = kThreads - dy * w;
+  const int dy = wg_size() / w, dx = wg_size() - dy * w;
   int y = tid / w, x = tid - y * w;
-  for (int i = tid; i < n; i += kThreads) {
+  for (int i = tid; i < n; i += wg_size()) {
     int y0 = y - th / 2, y1 = y0 + th, xa = x - tw / 2, xb = xa + tw;
     y0 = y0 < 0 ? 0 : y0;  y1 = y1 > h ? h : y1;  // (y0 <= h and y1 >= 0 always: 0 <= y < h, th >= 1)
     xa = xa < 0 ? 0 : xa;  xb = xb > w ? w : xb;
@@ -202,7 +205,7 @@ __device__ __forceinline__ void inv_sigma_map(const float* x0, int h, int w, int
   build_sat(x0, h, w, sat, false);
 #pragma unroll
   for (int k = 0; k < kMaxPixPerThread; ++k) {
-    const int i = tid + k * kThreads;
+    const int i = tid + k * wg_size();
     s1[k] = 0.0;
     if (i < n) {
       const int y = i / w, x = i - y * w;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void inv_sigma_map(const float* x0, int h, int w, int
   const double inv_n = 1.0 / (static_cast<double>(th) * static_cast<double>(tw));
 #pragma unroll
   for (int k = 0; k < kMaxPixPerThread; ++k) {
-    const int i = tid + k * kThreads;
+    const int i = tid + k * wg_size();
     if (i < n) {
       const int y = i / w, x = i - y * w;
       const double s2 = window_sum(sat, h, w, th, tw, y, x);

@@ -97,7 +97,7 @@ __device__ __forceinline__ float load_feature(const void* base, size_t idx, int 
   return static_cast<float>(v.h);
 }
 
-// Workgroup reductions over kThreads work-items; `scratch` holds kThreads/64 values.
+// Workgroup reductions over the launch's work-items (a multiple of 64); `scratch` holds one value per wave.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
   const int tid = static_cast<int>(threadIdx.x);
@@ -105,7 +105,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   if ((tid & 63) == 0) scratch[tid >> 6] = v;
   __syncthreads();
   double s = 0.0;
-  for (int w = 0; w < kThreads / 64; ++w) s += scratch[w];
+  for (int w = 0; w < static_cast<int>(blockDim.x) / 64; ++w) s += scratch[w];
   return s;
 }
 template <int NT = kThreads>
