@@ -69,8 +69,11 @@ __global__ void __launch_bounds__(kThreads)
 conv_first_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2,
                   float s0, float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias,
                   int relu, int nchw, float* __restrict__ out) {
-  __shared__ float patch[kPatch * kPatch * 3];
-  __shared__ float wl[27 * 64 + 64];
+  // Lane = output channel (its 27 weights live in registers), wave = strips of 8 output pixels: a strip reads
+  // its 3 x 10 x 3 input values with wave-uniform (broadcast) 16-byte LDS reads and does 216 FMAs on them, and a
+  // pixel's 64 channels leave as one 256-byte store.
+  constexpr int kRowF = 56;  // floats per patch row: 18 pixels x 3 planes, padded to 16-byte multiples
+  __shared__ __attribute__((aligned(16))) float patch[kPatch * kRowF];
   const int tiles_x = ceil_div(W, kTile);
   const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
   const int y0 = ty * kTile, x0 = tx * kTile;
@@ -88,33 +91,46 @@ conv_first_kernel(const uint8_t* __restrict__ images, int H, int W, int in_chann
         const float u = static_cast<float>(in_channels == 1 ? images[pix] : images[pix * 3 + c]);
         v = (u / 255.0f - mean[c]) * istd[c];  // ToTensor then Normalize, in this order (network.py:64-69)
       }
-      patch[i * 3 + c] = v;
+      patch[py * kRowF + px * 3 + c] = v;
     }
   }
-  for (int i = tid; i < 27 * 64; i += kThreads) wl[i] = wts[i];
-  for (int i = tid; i < 64; i += kThreads) wl[27 * 64 + i] = bias[i];
+  if (tid < kPatch) { patch[tid * kRowF + 54] = 0.0f; patch[tid * kRowF + 55] = 0.0f; }
+  const int n = tid & 63, wave = tid >> 6;
+  float w[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) w[k] = wts[k * 64 + n];  // packed [tap*3 + c][64]
+  const float b = bias[n];
   __syncthreads();
-  const int py = tid / kTile, px = tid % kTile;
-  const int y = y0 + py, x = x0 + px;
-  float acc[64];
+  for (int strip = wave; strip < 2 * kTile; strip += kThreads / 64) {
+    const int py = strip >> 1, px0 = (strip & 1) * 8;
+    float acc[8];
 #pragma unroll
-  for (int n = 0; n < 64; ++n) acc[n] = wl[27 * 64 + n];
-  for (int tap = 0; tap < 9; ++tap) {
-    const int dy = tap / 3, dx = tap % 3;
+    for (int i = 0; i < 8; ++i) acc[i] = b;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float v = patch[((py + dy) * kPatch + (px + dx)) * 3 + c];
-      const float* wr = wl + (tap * 3 + c) * 64;
+    for (int dy = 0; dy < 3; ++dy) {
+      const float4* row = reinterpret_cast<const float4*>(patch + (py + dy) * kRowF + px0 * 3);  // 30 floats used
+      float v[32];
 #pragma unroll
-      for (int n = 0; n < 64; ++n) acc[n] = fmaf(v, wr[n], acc[n]);
+      for (int k = 0; k < 8; ++k) {
+        const float4 r = row[k];
+        v[4 * k] = r.x; v[4 * k + 1] = r.y; v[4 * k + 2] = r.z; v[4 * k + 3] = r.w;
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = fmaf(v[(i + dx) * 3 + c], w[(dy * 3 + dx) * 3 + c], acc[i]);
     }
-  }
-  if (y < H && x < W) {
+    const int y = y0 + py;
 #pragma unroll
-    for (int n = 0; n < 64; ++n) {
-      const float v = relu ? fmaxf(acc[n], 0.0f) : acc[n];
-      if (nchw) out[((img * 64 + n) * H + y) * static_cast<size_t>(W) + x] = v;
-      else out[((img * H + y) * static_cast<size_t>(W) + x) * 64 + n] = v;
+    for (int i = 0; i < 8; ++i) {
+      const int x = x0 + px0 + i;
+      if (y < H && x < W) {
+        const float r = relu ? fmaxf(acc[i], 0.0f) : acc[i];
+        if (nchw) out[((img * 64 + n) * H + y) * static_cast<size_t>(W) + x] = r;
+        else out[((img * H + y) * static_cast<size_t>(W) + x) * 64 + n] = r;
+      }
     }
   }
 }
