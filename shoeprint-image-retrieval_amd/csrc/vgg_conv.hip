@@ -160,24 +160,47 @@ conv_mfma_kernel(const float* __restrict__ in, int H, int W, int cin, int cout, 
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* in_img = in + img * static_cast<size_t>(H) * W * cin;
-  for (int cc = 0; cc < nchunks; ++cc) {
-    __syncthreads();  // the previous chunk's fragments are consumed
-    // ---- stage the input patch: 324 pixels x 16 channels, one 16-byte piece per (pixel, quarter)
-    for (int i = tid; i < kPatch * kPatch * 4; i += kThreads) {
+  // Staging is software-pipelined: the 16-byte pieces of chunk cc+1 (input patch + filter slab) are requested
+  // into registers before the MFMA loop of chunk cc and written to LDS after it, so their HBM/L2 latency runs
+  // under ~18 k cycles of matrix work instead of in front of it.
+  constexpr int kPatchPieces = kPatch * kPatch * 4, kFilterPieces = 9 * kTN * 4;
+  constexpr int kPP = (kPatchPieces + kThreads - 1) / kThreads, kFP = kFilterPieces / kThreads;
+  static_assert(kFilterPieces % kThreads == 0, "filter slab pieces divide over the workgroup");
+  float4 pre_p[kPP];
+  auto request = [&](int cc) {
+#pragma unroll
+    for (int k = 0; k < kPP; ++k) {
+      const int i = tid + k * kThreads;
       const int pp = i >> 2, qq = i & 3;
       const int y = y0 - 1 + pp / kPatch, x = x0 - 1 + pp % kPatch;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (y >= 0 && y < H && x >= 0 && x < W)
+      if (i < kPatchPieces && y >= 0 && y < H && x >= 0 && x < W)
         v = *reinterpret_cast<const float4*>(in_img + (static_cast<size_t>(y) * W + x) * cin + cc * kCk + qq * 4);
-      *reinterpret_cast<float4*>(patch + pp * kCS + qq * 4) = v;
+      pre_p[k] = v;
     }
-    // ---- stage the filter slab [tap][n][16] of this (cout block, chunk): contiguous in the packed buffer
-    const float* wsrc = wts + (static_cast<size_t>(cb) * nchunks + cc) * (9 * kTN * kCk);
-    for (int i = tid; i < 9 * kTN * 4; i += kThreads) {
-      const int row = i >> 2, qq = i & 3;
-      *reinterpret_cast<float4*>(wl + row * kCS + qq * 4) = *reinterpret_cast<const float4*>(wsrc + row * kCk + qq * 4);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < kPP; ++k) {
+      const int i = tid + k * kThreads;
+      if (i < kPatchPieces) *reinterpret_cast<float4*>(patch + (i >> 2) * kCS + (i & 3) * 4) = pre_p[k];
+    }
+  };
+  request(0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // the previous chunk's fragments are consumed
+    commit();
+    {  // filter slab [tap][n][16] of this (cout block, chunk): contiguous in the packed buffer, L2-resident
+      const float* wsrc = wts + (static_cast<size_t>(cb) * nchunks + cc) * (9 * kTN * kCk);
+#pragma unroll
+      for (int k = 0; k < kFP; ++k) {
+        const int i = tid + k * kThreads;
+        *reinterpret_cast<float4*>(wl + (i >> 2) * kCS + (i & 3) * 4) =
+            *reinterpret_cast<const float4*>(wsrc + (i >> 2) * kCk + (i & 3) * 4);
+      }
     }
     __syncthreads();
+    if (cc + 1 < nchunks) request(cc + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
