@@ -54,8 +54,11 @@ enum spr_dtype { SPR_F32 = 0, SPR_F16 = 1, SPR_BF16 = 2 };
 
 /* Which pair kernel scores a (query, gallery) pair. */
 enum spr_ncc_method {
-  SPR_NCC_AUTO = 0,   /* FFT when the padded maps fit the LDS-resident FFT, else direct */
-  SPR_NCC_FFT = 1,    /* frequency-domain correlation, LDS-resident inverse 2-D FFT per channel */
+  SPR_NCC_AUTO = 0,   /* FFT when an instantiated grid covers the padded maps, else direct */
+  SPR_NCC_FFT = 1,    /* frequency-domain correlation, inverse 2-D FFT per channel: LDS-resident for maps up to
+                         ~12 k cropped pixels, working set in a plan-owned device workspace beyond that (maps
+                         up to 256 x 128 on the 384 x 192 grid); the plan allocates the workspace itself and
+                         spr_ncc_plan_create returns SPR_ERR_WORKSPACE if that allocation fails */
   SPR_NCC_DIRECT = 2, /* sliding-window correlation in LDS (any shape that fits LDS) */
   SPR_NCC_FFT_POW2 = 3 /* as SPR_NCC_FFT but restricted to power-of-two grids (A/B and fallback for the 3*2^k grids) */
 };

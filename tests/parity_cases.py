@@ -183,6 +183,27 @@ def check_big_mode(make_scorer, monkeypatch, full):
     np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
 
 
+def check_empty_and_degenerate_sets(scorer):
+    """Edge cases as the reference behaves (run there): no queries -> empty int32 ranks; one query works;
+    queries against an empty gallery -> IndexError from the rank lookup (similarity.py:386); a match index
+    outside the gallery -> IndexError as well."""
+    g = [synth.gallery_features(71, i, 2, 12, 10) for i in range(3)]
+    q = [synth.query_features(71, i, i, 2, 12, 10) for i in range(2)]
+    r = similarity.compare_maps([], g, [], _cfg(), scorer=scorer)
+    assert r.dtype == np.int32 and r.shape == (0,)
+    one = similarity.compare_maps(q[:1], g, [0], _cfg(), scorer=scorer)
+    np.testing.assert_array_equal(one, oracle.compare_maps(q[:1], g, [0], _cfg()))
+    for bad in (lambda: similarity.compare_maps(q, [], [0, 1], _cfg(), scorer=scorer),
+                lambda: similarity.compare_maps(q, g, [0, 7], _cfg(), scorer=scorer)):
+        try:
+            bad()
+        except IndexError:
+            pass
+        else:
+            raise AssertionError("expected IndexError")
+    assert scorer.score_matrix([], g).shape == (0, 3) and scorer.score_matrix(q, []).shape == (2, 0)
+
+
 def check_rank_kernel(scorer):
     rng = np.random.default_rng(5)
     for nq, ng in [(1, 1), (3, 7), (5, 300), (2, 1500)]:

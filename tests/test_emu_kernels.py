@@ -56,6 +56,10 @@ def test_emu_big_mode(monkeypatch):
     pc.check_big_mode(lambda: emu_scorer("fft"), monkeypatch, full=False)
 
 
+def test_emu_empty_and_degenerate_sets():
+    pc.check_empty_and_degenerate_sets(emu_scorer("auto"))
+
+
 def test_emu_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 

@@ -85,6 +85,10 @@ def test_big_mode(lib, monkeypatch):
     pc.check_big_mode(lambda: NccScorer(method="fft", library=lib), monkeypatch, full=True)
 
 
+def test_empty_and_degenerate_sets(fft_scorer):
+    pc.check_empty_and_degenerate_sets(fft_scorer)
+
+
 def test_rank_kernel(scorer):
     pc.check_rank_kernel(scorer)
 
