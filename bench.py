@@ -239,6 +239,12 @@ def main():
         out["parity_sample"] = {"pairs": len(errs), "max_abs_err_vs_oracle": float(f"{max(errs):.3e}"), "tolerance": 1e-4}
     if rank == 0:
         print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:  # leave the group together (rank 0 ran the extra legs above) and tear RCCL down cleanly
+        import torch.distributed as dist
+
+        sdist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

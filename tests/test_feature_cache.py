@@ -12,7 +12,7 @@ def test_round_trip_ragged_and_key(tmp_path):
     key = {"block": 16, "scale": 0.78125, "crop": [0.1, 0.2], "files": ["001.png", "002.png", "003.png"]}
     fc.save_features(path, maps, key)
     got = fc.load_features(path, key)
-    assert len(got) == 3 and all(isinstance(g, np.memmap) or isinstance(g.base, np.memmap) or True for g in got)
+    assert len(got) == 3
     for a, b in zip(maps, got):
         np.testing.assert_array_equal(a, b)
         assert b.dtype == np.float32 and b.flags["C_CONTIGUOUS"]
