@@ -180,6 +180,15 @@ int spr_clahe_u8(const uint8_t* in, uint8_t* out, int64_t n, int32_t h, int32_t 
 
 typedef struct spr_vgg16_plan spr_vgg16_plan;
 
+/* Plain-VGG backbones of network.py:121-139: the truncation model.features[:block] of torchvision's vgg16
+ * (cfg "D"), vgg19 (cfg "E") or vgg19_bn.  The plan type keeps its first name; spr_vgg16_plan_create(block)
+ * is spr_vgg_plan_create(SPR_VGG16, block).  BatchNorm2d (eval mode) is folded into the preceding
+ * convolution's weights and bias by the caller when spr_vgg_conv_info reports it inside the truncation. */
+typedef enum spr_vgg_arch { SPR_VGG16 = 0, SPR_VGG19 = 1, SPR_VGG19_BN = 2 } spr_vgg_arch;
+int spr_vgg_plan_create(int32_t arch, int32_t block, spr_vgg16_plan** plan_out);
+/* For convolution conv_index: its position in model.features (state-dict key features.<k>.weight) and whether
+ * the BatchNorm2d that follows it (features.<k+1>) lies inside features[:block]. */
+int spr_vgg_conv_info(const spr_vgg16_plan* plan, int32_t conv_index, int32_t* feature_index, int32_t* bn_inside);
 int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out);
 void spr_vgg16_plan_destroy(spr_vgg16_plan* plan);
 /* Number of convolution layers inside features[:block] and their (cin, cout). */

@@ -14,39 +14,50 @@ import torch
 import torch.nn.functional as F
 
 VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
-MEAN = (0.48235, 0.45882, 0.40784)
+VGG19_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
+MEAN = (0.48235, 0.45882, 0.40784)          # network.py:128 (VGG16)
 STD = (0.00392156862745098,) * 3
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # network.py:52-53 (VGG19, VGG19_BN)
+ARCHS = {"VGG16": (VGG16_CFG, False, MEAN, STD), "VGG19": (VGG19_CFG, False, IMAGENET_MEAN, IMAGENET_STD),
+         "VGG19_BN": (VGG19_CFG, True, IMAGENET_MEAN, IMAGENET_STD)}
 
 
-def feature_ops(block: int):
+def feature_ops(block: int, arch: str = "VGG16"):
+    cfg, bn, _, _ = ARCHS[arch]
     ops, cin = [], 3
-    for v in VGG16_CFG:
+    for v in cfg:
         if v == "M":
             ops.append(("pool",))
         else:
             ops.append(("conv", cin, v))
+            if bn:
+                ops.append(("bn", v))
             ops.append(("relu",))
             cin = v
     return ops[:block]
 
 
-def conv_shapes(block: int):
-    return [(op[1], op[2]) for op in feature_ops(block) if op[0] == "conv"]
+def conv_shapes(block: int, arch: str = "VGG16"):
+    return [(op[1], op[2]) for op in feature_ops(block, arch) if op[0] == "conv"]
 
 
-def get_feature_maps(img: np.ndarray, block: int, parameters) -> np.ndarray:
-    """uint8 [H,W] (already CLAHE'd) -> float32 [C,h,w]."""
+def get_feature_maps(img: np.ndarray, block: int, parameters, arch: str = "VGG16") -> np.ndarray:
+    """uint8 [H,W] (already CLAHE'd) -> float32 [C,h,w].  ``parameters[i]`` = (w, b) or, for a convolution whose
+    BatchNorm2d is part of the truncation, (w, b, gamma, beta, running_mean, running_var)."""
     x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None].repeat(3, 1, 1)  # ToTensor + repeat
-    mean = torch.tensor(MEAN, dtype=torch.float32)[:, None, None]
-    std = torch.tensor(STD, dtype=torch.float32)[:, None, None]
+    mean = torch.tensor(ARCHS[arch][2], dtype=torch.float32)[:, None, None]
+    std = torch.tensor(ARCHS[arch][3], dtype=torch.float32)[:, None, None]
     x = ((x - mean) / std)[None]
     k = 0
     with torch.no_grad():
-        for op in feature_ops(block):
+        for op in feature_ops(block, arch):
             if op[0] == "conv":
-                w, b = parameters[k]
+                p = parameters[k]
                 k += 1
-                x = F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), stride=1, padding=1)
+                x = F.conv2d(x, torch.from_numpy(p[0]), torch.from_numpy(p[1]), stride=1, padding=1)
+            elif op[0] == "bn":
+                gamma, beta, mu, var = (torch.from_numpy(t) for t in parameters[k - 1][2:])
+                x = F.batch_norm(x, mu, var, gamma, beta, training=False, eps=1e-5)
             elif op[0] == "relu":
                 x = F.relu(x)
             else:

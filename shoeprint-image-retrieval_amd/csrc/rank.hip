@@ -56,7 +56,8 @@ extern "C" int spr_rank_true_match(const float* scores, int64_t ld, int64_t n_qu
   using namespace spr;
   if (n_queries < 0 || n_gallery < 0 || ld < n_gallery) { set_error("spr_rank_true_match: bad sizes"); return SPR_ERR_ARG; }
   if (n_queries == 0) return SPR_OK;
-  if (!scores || !match || !ranks) { set_error("spr_rank_true_match: null pointer"); return SPR_ERR_ARG; }
+  // (an empty gallery has no score storage: every rank then comes back 0 = "match not in the gallery")
+  if ((!scores && n_gallery > 0) || !match || !ranks) { set_error("spr_rank_true_match: null pointer"); return SPR_ERR_ARG; }
   hipLaunchKernelGGL(rank_kernel, dim3(static_cast<unsigned>(n_queries)), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), scores, static_cast<long long>(ld),
                      static_cast<long long>(n_gallery), 0LL, static_cast<const float*>(nullptr), match, ranks, 1);

@@ -275,25 +275,43 @@ constexpr size_t kConvLds = sizeof(float) * (kPatch * kPatch * kCS + 9 * kTN * k
 struct spr_vgg16_plan {
   int block;
   std::vector<spr::Stage> stages;
+  std::vector<int> feature_index;  // position of every convolution in model.features
+  std::vector<int> bn_inside;      // 1: its BatchNorm2d lies inside features[:block] (folded by the host)
   size_t packed_floats;
 };
 
 using namespace spr;
 
-extern "C" int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out) {
-  if (!plan_out) { set_error("spr_vgg16_plan_create: null pointer"); return SPR_ERR_ARG; }
+// torchvision configurations: "D" (vgg16) and "E" (vgg19); *_bn puts a BatchNorm2d between every convolution
+// and its ReLU.  BatchNorm in eval mode is an affine map per channel: the host folds it into the convolution's
+// weights and bias when the layer lies inside features[:block], so the kernels never see it.
+extern "C" int spr_vgg_plan_create(int32_t arch, int32_t block, spr_vgg16_plan** plan_out) {
+  if (!plan_out) { set_error("spr_vgg_plan_create: null pointer"); return SPR_ERR_ARG; }
   *plan_out = nullptr;
-  // torchvision vgg16 cfg "D": 64,64,M,128,128,M,256,256,256,M,512,512,512,M,512,512,512,M
-  static const int cfg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -1, 512, 512, 512, -1, 512, 512, 512, -1};
+  static const int cfg_d[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -1, 512, 512, 512, -1, 512, 512, 512, -1};
+  static const int cfg_e[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, 256, -1,
+                              512, 512, 512, 512, -1, 512, 512, 512, 512, -1};
+  const int* cfg = cfg_d;
+  int n_cfg = static_cast<int>(sizeof(cfg_d) / sizeof(int));
+  bool bn = false;
+  if (arch == SPR_VGG19 || arch == SPR_VGG19_BN) { cfg = cfg_e; n_cfg = static_cast<int>(sizeof(cfg_e) / sizeof(int)); }
+  else if (arch != SPR_VGG16) { set_error("spr_vgg_plan_create: unknown architecture %d", arch); return SPR_ERR_ARG; }
+  if (arch == SPR_VGG19_BN) bn = true;
   struct Op { char kind; int cin, cout; };
   std::vector<Op> ops;
   int c = 3;
-  for (int v : cfg) {
+  for (int k = 0; k < n_cfg; ++k) {
+    const int v = cfg[k];
     if (v < 0) ops.push_back({'P', c, c});
-    else { ops.push_back({'C', c, v}); ops.push_back({'R', v, v}); c = v; }
+    else {
+      ops.push_back({'C', c, v});
+      if (bn) ops.push_back({'B', v, v});
+      ops.push_back({'R', v, v});
+      c = v;
+    }
   }
   if (block < 1 || block > static_cast<int>(ops.size())) {
-    set_error("spr_vgg16_plan_create: block %d outside [1, %zu] (len(vgg16.features) = 31)", block, ops.size());
+    set_error("spr_vgg_plan_create: block %d outside [1, %zu] (= len(model.features))", block, ops.size());
     return SPR_ERR_ARG;
   }
   spr_vgg16_plan* plan = new (std::nothrow) spr_vgg16_plan();
@@ -301,22 +319,41 @@ extern "C" int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out) {
   plan->block = block;
   size_t off = 0;
   for (int i = 0; i < block; ++i) {
-    if (ops[i].kind != 'C') continue;  // R and P are fused into the preceding convolution
+    if (ops[i].kind != 'C') continue;  // B is folded by the host, R and P are fused into the preceding convolution
     Stage s{};
     s.cin = ops[i].cin; s.cout = ops[i].cout;
-    s.relu = (i + 1 < block && ops[i + 1].kind == 'R') ? 1 : 0;
-    s.pool = (s.relu && i + 2 < block && ops[i + 2].kind == 'P') ? 1 : 0;
+    int j = i + 1;
+    const bool has_bn = j < block && ops[j].kind == 'B';
+    if (has_bn) ++j;
+    s.relu = (j < block && ops[j].kind == 'R') ? 1 : 0;
+    s.pool = (s.relu && j + 1 < block && ops[j + 1].kind == 'P') ? 1 : 0;
     s.w_off = off; off += static_cast<size_t>(s.cout) * s.cin * 9;
     s.b_off = off; off += static_cast<size_t>(s.cout);
     off = (off + 3) / 4 * 4;  // keep every slab 16-byte aligned
     plan->stages.push_back(s);
+    plan->feature_index.push_back(i);
+    plan->bn_inside.push_back(has_bn ? 1 : 0);
   }
   plan->packed_floats = off;
   *plan_out = plan;
   return SPR_OK;
 }
 
+extern "C" int spr_vgg16_plan_create(int32_t block, spr_vgg16_plan** plan_out) {
+  return spr_vgg_plan_create(SPR_VGG16, block, plan_out);
+}
+
 extern "C" void spr_vgg16_plan_destroy(spr_vgg16_plan* plan) { delete plan; }
+
+extern "C" int spr_vgg_conv_info(const spr_vgg16_plan* plan, int32_t i, int32_t* feature_index, int32_t* bn_inside) {
+  if (!plan || !feature_index || !bn_inside || i < 0 || i >= static_cast<int>(plan->stages.size())) {
+    set_error("spr_vgg_conv_info: bad argument");
+    return SPR_ERR_ARG;
+  }
+  *feature_index = plan->feature_index[i];
+  *bn_inside = plan->bn_inside[i];
+  return SPR_OK;
+}
 
 extern "C" int spr_vgg16_num_convs(const spr_vgg16_plan* plan) {
   return plan ? static_cast<int>(plan->stages.size()) : SPR_ERR_ARG;

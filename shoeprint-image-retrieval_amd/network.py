@@ -32,8 +32,13 @@ from . import _lib, synth
 
 VGG16_MEAN = (0.48235, 0.45882, 0.40784)                     # network.py:128
 VGG16_STD = (0.00392156862745098,) * 3                       # network.py:129
-_CONV_INDEX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)   # positions of the convolutions in vgg16().features
-_REFERENCE_MODELS = {"VGG19", "VGG19_BN", "EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
+IMAGENET_MEAN = (0.485, 0.456, 0.406)                        # network.py:52 (the default transforms)
+IMAGENET_STD = (0.229, 0.224, 0.225)                         # network.py:53
+BN_EPS = 1e-5                                                # torch.nn.BatchNorm2d default
+# model.type -> (spr_vgg_arch, mean, std): the plain-VGG branches of network.py:121-139
+_VGG_MODELS = {"VGG16": (0, VGG16_MEAN, VGG16_STD), "VGG19": (1, IMAGENET_MEAN, IMAGENET_STD),
+               "VGG19_BN": (2, IMAGENET_MEAN, IMAGENET_STD)}
+_REFERENCE_MODELS = {"EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
                      "EfficientNet_B5", "EfficientNet_B7", "EfficientNetV2_S", "EfficientNetV2_M", "EfficientNetV2_L",
                      "DenseNet_201"}
 _warned = False
@@ -49,11 +54,13 @@ class Model:
         self.clahe_clip_limit = float(model_cfg.get("clahe_clip_limit", 2.0))
         self.clahe_tile_grid_size = tuple(model_cfg.get("clahe_tile_grid_size", (8, 8)))
         model_str = model_cfg["type"]
-        if model_str != "VGG16":
+        if model_str not in _VGG_MODELS:
             if model_str in _REFERENCE_MODELS:
-                raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); use VGG16")
+                raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); "
+                                          f"use one of {sorted(_VGG_MODELS)}")
             raise LookupError("Model string not found")  # network.py:180-182
-        self.mean, self.std = VGG16_MEAN, VGG16_STD
+        self.model_str = model_str
+        self.arch, self.mean, self.std = _VGG_MODELS[model_str]
         self.block = int(block)
         self.batch_size = int(batch_size)
         self.lib = library or _lib.load_library()
@@ -63,7 +70,7 @@ class Model:
             device = TorchDevice()
         self.dev = device
         handle = C.c_void_p()
-        self.lib.check(self.lib.spr_vgg16_plan_create(self.block, C.byref(handle)))
+        self.lib.check(self.lib.spr_vgg_plan_create(self.arch, self.block, C.byref(handle)))
         self.handle = handle
         self.n_convs = self.lib.spr_vgg16_num_convs(handle)
         if parameters is None:
@@ -79,6 +86,15 @@ class Model:
             out.append((cin.value, cout.value))
         return out
 
+    def conv_info(self) -> list[tuple[int, bool]]:
+        """(index in model.features, BatchNorm2d inside the truncation) of every convolution."""
+        out = []
+        for i in range(self.n_convs):
+            k, bn = C.c_int32(), C.c_int32()
+            self.lib.check(self.lib.spr_vgg_conv_info(self.handle, i, C.byref(k), C.byref(bn)))
+            out.append((k.value, bool(bn.value)))
+        return out
+
     def _load_parameters(self, config):
         global _warned
         path = config.get("mi355x", {}).get("weights", "")
@@ -87,15 +103,18 @@ class Model:
 
             state = torch.load(path, map_location="cpu", weights_only=True)
             params = []
-            for i in range(self.n_convs):
-                k = _CONV_INDEX[i]
-                params.append((state[f"features.{k}.weight"].float().numpy(), state[f"features.{k}.bias"].float().numpy()))
+            for k, bn in self.conv_info():
+                p = [state[f"features.{k}.weight"].float().numpy(), state[f"features.{k}.bias"].float().numpy()]
+                if bn:  # BatchNorm2d at features.<k+1>: gamma, beta, running mean, running variance
+                    p += [state[f"features.{k + 1}.{n}"].float().numpy()
+                          for n in ("weight", "bias", "running_mean", "running_var")]
+                params.append(tuple(p))
             return params
         if not _warned:
-            print("shoeprint_image_retrieval_amd: no [mi355x].weights given — using seeded synthetic VGG16 weights "
-                  "(pretrained IMAGENET1K_FEATURES cannot be downloaded offline)", file=sys.stderr)
+            print(f"shoeprint_image_retrieval_amd: no [mi355x].weights given — using seeded synthetic {self.model_str} "
+                  "weights (pretrained ImageNet weights cannot be downloaded offline)", file=sys.stderr)
             _warned = True
-        return synth.vgg16_parameters(1234, self.conv_shapes())
+        return synth.vgg_parameters(1234, self.conv_shapes(), [bn for _, bn in self.conv_info()])
 
     def _set_parameters(self, parameters):
         shapes = self.conv_shapes()
@@ -103,9 +122,18 @@ class Model:
             raise ValueError(f"{len(shapes)} convolutions need parameters, got {len(parameters)}")
         dev = self.dev
         self._w_dev, self._b_dev = [], []
-        for (cin, cout), (w, b) in zip(shapes, parameters):
-            w = np.ascontiguousarray(w, dtype=np.float32)
-            b = np.ascontiguousarray(b, dtype=np.float32)
+        for (cin, cout), (_, bn), p in zip(shapes, self.conv_info(), parameters):
+            w = np.ascontiguousarray(p[0], dtype=np.float32)
+            b = np.ascontiguousarray(p[1], dtype=np.float32)
+            if bn:
+                # eval-mode BatchNorm2d after the convolution is y = (x - mean) * gamma / sqrt(var + eps) + beta:
+                # folded into the convolution (float32, as the layer itself computes)
+                if len(p) != 6:
+                    raise ValueError("a convolution followed by BatchNorm2d needs (w, b, gamma, beta, mean, var)")
+                gamma, beta, mu, var = (np.asarray(t, dtype=np.float32) for t in p[2:])
+                scale = gamma / np.sqrt(var + np.float32(BN_EPS))
+                w = np.ascontiguousarray(w * scale[:, None, None, None])
+                b = np.ascontiguousarray((b - mu) * scale + beta)
             if w.shape != (cout, cin, 3, 3) or b.shape != (cout,):
                 raise ValueError(f"parameter shape {w.shape}/{b.shape} does not match conv {cin}->{cout}")
             self._w_dev.append(dev.to_device(w))

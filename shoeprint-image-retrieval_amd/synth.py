@@ -130,6 +130,28 @@ def vgg16_parameters(seed: int, conv_shapes) -> list[tuple[np.ndarray, np.ndarra
     return params
 
 
+def vgg_parameters(seed: int, conv_shapes, bn_flags=None):
+    """``vgg16_parameters`` plus, where ``bn_flags[i]`` is set, BatchNorm2d parameters (gamma ~ 1 +- 0.1, beta and
+    running mean small, running variance in [0.6, 1.4]) for the convolution's BatchNorm layer."""
+    params = vgg16_parameters(seed, conv_shapes)
+    if not bn_flags:
+        return params
+    out = []
+    for i, ((w, b), bn) in enumerate(zip(params, bn_flags)):
+        if not bn:
+            out.append((w, b))
+            continue
+        idx = np.arange(w.shape[0], dtype=np.int64)
+        u = [irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 1000 + 4 * i + k), idx).astype(np.float32) / np.float32(37837.0)
+             for k in range(4)]  # ~N(0,1) each
+        gamma = np.float32(1.0) + np.float32(0.1) * np.clip(u[0], -3, 3)
+        beta = np.float32(0.05) * u[1]
+        mean = np.float32(0.1) * u[2]
+        var = np.float32(1.0) + np.float32(0.4) * np.tanh(u[3])
+        out.append((w, b, gamma.astype(np.float32), beta.astype(np.float32), mean.astype(np.float32), var.astype(np.float32)))
+    return out
+
+
 def bfloat16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bfloat16 bit patterns (uint16), round to nearest even — the storage form the scorer
     accepts for bf16 features (numpy has no bfloat16 type)."""

@@ -29,6 +29,22 @@ def check_block(block, hw, device, lib, n_images=2):
     m.close()
 
 
+def check_other_vgg(arch, block, hw, device, lib):
+    """VGG19 / VGG19_BN truncations (reference network.py:121-139) against the torch-CPU oracle, including cuts
+    between a convolution and its BatchNorm and between the BatchNorm and its ReLU."""
+    cfg = {"model": dict(CFG["model"], type=arch), "comparison": CFG["comparison"]}
+    m = network.Model(cfg, block, device=device, library=lib)
+    assert m.conv_shapes() == vgg_oracle.conv_shapes(block, arch)
+    params = synth.vgg_parameters(1234, m.conv_shapes(), [bn for _, bn in m.conv_info()])
+    imgs = np.stack([synth.shoeprint_image(6, i, *hw) for i in range(2)])
+    got = device.to_host(m.extract_device(device.to_device(imgs)))
+    for i in range(2):
+        ref = vgg_oracle.get_feature_maps(imgs[i], block, params, arch)
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+    m.close()
+
+
 def check_reference_surface(device, lib):
     """Model(config, block), get_feature_maps, get_multiple_feature_maps keep the reference's behaviour."""
     m = make_model(5, device, lib, batch_size=2)
@@ -42,7 +58,7 @@ def check_reference_surface(device, lib):
         np.testing.assert_allclose(fm, ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
     single = m.get_feature_maps(imgs[1])
     np.testing.assert_array_equal(single, maps[1])
-    for bad, exc in (("NoSuchNet", LookupError), ("EfficientNetV2_M", NotImplementedError)):
+    for bad, exc in (("NoSuchNet", LookupError), ("EfficientNetV2_M", NotImplementedError), ("DenseNet_201", NotImplementedError)):
         cfg = {"model": dict(CFG["model"], type=bad)}
         try:
             network.Model(cfg, 5, device=device, library=lib)

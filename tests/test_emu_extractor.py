@@ -21,6 +21,12 @@ def test_emu_vgg16_conv3_3_block16():
     ec.check_block(16, (32, 48), HostDevice(), emu_library(), n_images=1)
 
 
+@pytest.mark.parametrize("arch,block,hw", [("VGG19", 12, (24, 32)), ("VGG19", 19, (32, 32)), ("VGG19_BN", 1, (18, 20)),
+                                           ("VGG19_BN", 2, (18, 20)), ("VGG19_BN", 3, (20, 18)), ("VGG19_BN", 14, (24, 24))])
+def test_emu_other_vgg_backbones(arch, block, hw):
+    ec.check_other_vgg(arch, block, hw, HostDevice(), emu_library())
+
+
 def test_emu_reference_surface():
     ec.check_reference_surface(HostDevice(), emu_library())
 

@@ -197,6 +197,14 @@ def test_vgg16_conv3_3_full_size_image(torch_dev, lib):
     ec.check_block(16, (512, 256), torch_dev, lib, n_images=1)
 
 
+@pytest.mark.parametrize("arch,block,hw", [("VGG19", 19, (64, 48)), ("VGG19", 37, (64, 64)), ("VGG19_BN", 2, (40, 36)),
+                                           ("VGG19_BN", 27, (64, 48)), ("VGG19_BN", 53, (64, 64))])
+def test_other_vgg_backbones(arch, block, hw, torch_dev, lib):
+    import extractor_cases as ec
+
+    ec.check_other_vgg(arch, block, hw, torch_dev, lib)
+
+
 def test_extractor_reference_surface(torch_dev, lib):
     import extractor_cases as ec
 
