@@ -50,6 +50,15 @@ class TorchDevice:
     def to_device(self, array: np.ndarray):
         return self.torch.from_numpy(np.ascontiguousarray(array)).to(self.device, non_blocking=False)
 
+    def stack_to_device(self, items):
+        """float32 device batch [N, ...] from a list of equally shaped host arrays, copied item by item straight
+        into the device tensor (no stacked host copy first: the host pass is the slow part of this boundary)."""
+        first = np.asarray(items[0])
+        out = self.torch.empty((len(items),) + tuple(first.shape), dtype=self.torch.float32, device=self.device)
+        for k, it in enumerate(items):
+            out[k].copy_(self.torch.from_numpy(np.ascontiguousarray(it, dtype=np.float32)))
+        return out
+
     def to_host(self, buf) -> np.ndarray:
         return buf.detach().cpu().numpy()
 

@@ -227,7 +227,7 @@ class NccScorer:
 
         builder = VariantBuilder(self.lib, self.dev)
         for qshape, q_idx in q_groups.items():
-            q_batch = self.dev.to_device(_stack32(q_items, q_idx))
+            q_batch = self.dev.stack_to_device([q_items[i] for i in q_idx])
             variants = builder.variants(q_batch, rotations, scales)
             by_shape: dict[tuple, list] = {}  # variants of one shape share a plan and the prepared gallery
             for v in variants:
@@ -239,7 +239,7 @@ class NccScorer:
                 chunk = min(self.gallery_chunk_items(p, len(g_idx)) for p in plans.values())
                 for start in range(0, len(g_idx), chunk):
                     idx = g_idx[start:start + chunk]
-                    g_batch = self.dev.to_device(_stack32(g_items, idx))
+                    g_batch = self.dev.stack_to_device([g_items[i] for i in idx])
                     sub = self.dev.zeros((len(q_idx), len(idx)), np.float32)
                     for vs, vlist in by_shape.items():
                         plan = plans[vs]
@@ -284,10 +284,6 @@ def _group_by_shape(items) -> dict[tuple, list[int]]:
             raise ValueError("feature maps must be [C, h, w] (customtypes.py:11-14)")
         groups.setdefault(tuple(a.shape), []).append(i)
     return groups
-
-
-def _stack32(items, idx) -> np.ndarray:
-    return np.ascontiguousarray(np.stack([np.asarray(items[i], dtype=np.float32) for i in idx]))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -23,6 +23,9 @@ class HostDevice:
     def to_device(self, array):
         return np.array(array, copy=True, order="C")
 
+    def stack_to_device(self, items):
+        return np.ascontiguousarray(np.stack([np.asarray(i, dtype=np.float32) for i in items]))
+
     def to_host(self, buf):
         return np.array(buf, copy=True)
 
