@@ -721,7 +721,9 @@ int prep_launch(const NccGeom& g, bool is_query, const void* maps, int64_t n, vo
 template <class C>
 int prep_t(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h, const cf* tw_w,
            const FftWorkspace& ws, hipStream_t stream) {
+#ifndef SPR_SAN_SUBSET
   if (g.big) return prep_launch<C, true, kThreads>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
+#endif
   if (prep_threads<C>(g, is_query) == 512)
     return prep_launch<C, false, 512>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
   return prep_launch<C, false, kThreads>(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
@@ -806,12 +808,14 @@ template <class C, int PFA>
 int pair_t(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
            int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
            unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
+#ifndef SPR_SAN_SUBSET  // (the sanitizer build of the CPU emulation compiles the default schedule only)
   if (g.big)
     return pair_tb<C, PFA, true, true>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
                                        team_sync, ws, stream);
   if (team_sync && !maps_out && env_int("SPR_NCC_TEAM", 0) == 1)
     return pair_tb<C, PFA, false, true>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
                                         team_sync, ws, stream);
+#endif
   return pair_tb<C, PFA, false, false>(g, tuned, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w,
                                        team_sync, ws, stream);
 }
@@ -832,6 +836,13 @@ constexpr FftEntry entry() {
 // -> 1.22 M (48 x 24, one wave);  conv4_3 maps [512,64,32]  255 k (128 x 64, 256 lanes) -> 295 k (96 x 48,
 // 256 lanes) -> 307 k (96 x 48, 192 lanes);  one wave per pair on 128 x 64 spills: 69 k.
 //                 EH TGH EW TGW  NT KWA RRA      prefetch buffers of the tuned variant
+#ifdef SPR_SAN_SUBSET  // sanitizer build: one grid of each workgroup shape keeps its compile time in minutes
+const FftEntry kEntries[] = {
+    entry<Cfg<8, 4, 4, 4, 64, 2, 1>, 1>(),
+    entry<Cfg<12, 8, 6, 8, 192, 5, 2>, 1>(),
+    entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),
+};
+#else
 const FftEntry kEntries[] = {
     entry<Cfg<8, 4, 4, 4, 64, 2, 1>, 1>(),        // 32 x 16   (grids this small: one WAVE per pair, no workgroup
     entry<Cfg<8, 4, 8, 4, 64, 2, 1>, 1>(),        // 32 x 32    barriers, up to 16 independent waves per CU)
@@ -846,6 +857,7 @@ const FftEntry kEntries[] = {
     entry<Cfg<24, 16, 12, 16, 512, 11, 4>, 1, true>(),  // 384 x 192: maps up to 256 x 128 (conv3_3 of a 1024x512 print,
                                                         // conv2_2 of 512x256); working set in the global workspace
 };
+#endif
 
 const FftEntry* find_entry(int nh, int nw) {
   for (const FftEntry& e : kEntries)
@@ -896,7 +908,12 @@ bool fft_geometry(NccGeom& g, bool pow2_only) {
   // smallest grid whose working set fits LDS; failing that, smallest grid with the working set in the global
   // workspace ("big" mode: any size the largest grid covers).  SPR_NCC_FORCE_BIG=1 skips the first pass (tests).
   const bool force_big = env_int("SPR_NCC_FORCE_BIG", 0) == 1;
-  for (int pass = force_big ? 1 : 0; pass < 2 && !best; ++pass) {
+#ifdef SPR_SAN_SUBSET
+  constexpr int kPasses = 1;  // the workspace kernels are not compiled into the sanitizer build
+#else
+  constexpr int kPasses = 2;
+#endif
+  for (int pass = force_big ? 1 : 0; pass < kPasses && !best; ++pass) {
     for (const FftEntry& e : kEntries) {
       if (e.nh < min_h || e.nw < min_w) continue;
       if (pow2_only && !e.pow2) continue;

@@ -37,7 +37,7 @@ def build(sanitize: bool | None = None, verbose: bool = False) -> str:
     if sanitize:
         # trap mode: no sanitizer runtime has to be linked into (or preloaded for) the shared object; any
         # undefined behaviour executes a trap instruction and kills the test process
-        flags += ["-fsanitize=undefined", "-fsanitize-trap=undefined", "-O1"]
+        flags += ["-fsanitize=undefined", "-fsanitize-trap=undefined", "-O1", "-DSPR_SAN_SUBSET"]
     objs = []
     procs = []
     for s in srcs:
