@@ -18,15 +18,31 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
   const int tid = static_cast<int>(threadIdx.x);
   const int n = h * w;
   double s = 0.0;
-  // (y, x) of pixel i = tid + k*wg_size() advance incrementally: one division per lane, not per pixel
-  const int dy = wg_size() / w, dx = wg_size() - dy * w;
+  // (y, x) of pixel i = tid + k*wg_size() advance incrementally: one division per lane, not per pixel.
+  // Eight loads are requested before the first is used, so a lane waits for HBM/L2 once per batch, not per pixel.
+  const int nthr = wg_size();
+  const int dy = nthr / w, dx = nthr - dy * w;
   int y = tid / w, x = tid - y * w;
-  for (int i = tid; i < n; i += wg_size()) {
-    const float v = load_feature(maps, chan_base + static_cast<size_t>(y + crop) * raw_w + (x + crop), dtype);
-    x0[i] = v;
-    s += static_cast<double>(v);
-    x += dx; y += dy;
-    if (x >= w) { x -= w; ++y; }
+  constexpr int B = 8;
+  for (int i0 = tid; i0 < n; i0 += B * nthr) {
+    float v[B];
+    int yy = y, xx = x;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      v[k] = i0 + k * nthr < n
+                 ? load_feature(maps, chan_base + static_cast<size_t>(yy + crop) * raw_w + (xx + crop), dtype)
+                 : 0.0f;
+      xx += dx; yy += dy;
+      if (xx >= w) { xx -= w; ++yy; }
+    }
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      if (i0 + k * nthr < n) {
+        x0[i0 + k * nthr] = v[k];
+        s += static_cast<double>(v[k]);
+      }
+    }
+    y = yy; x = xx;
   }
   const double total = block_sum(s, red);
   const float mean = static_cast<float>(total / static_cast<double>(n));
