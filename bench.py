@@ -226,17 +226,19 @@ def main():
                                "sample": f"Q={sq} x G={sg} of the same workload, oracle compare_maps with a "
                                          f"{cores}-process pool, {secs:.1f} s",
                                "gpu_over_cpu": round(value / v, 1)}
-    if rank == 0 and not args.no_parity_sample:
-        # parity spot-check on pairs of the ACTUAL workload (features regenerated by the numpy twin)
-        from oracle import ncc_oracle as oracle
-        full_h = dev.to_host(full)
-        errs = []
-        for qi in (0, nq - 1):
-            qf = synth.query_features(SEED, qi, int(matches[qi]), C, H, W)
-            for gi in (int(matches[qi]), (int(matches[qi]) + 1) % ng_total):
-                ref = max(0.0, float(oracle.get_similarity(qf, synth.gallery_features(SEED, gi, C, H, W), precise=True)))
-                errs.append(abs(ref - float(full_h[qi, gi])))
-        out["parity_sample"] = {"pairs": len(errs), "max_abs_err_vs_oracle": float(f"{max(errs):.3e}"), "tolerance": 1e-4}
+        if not args.no_parity_sample:
+            # same leg, same checker: the oracle on pairs of the ACTUAL workload (features regenerated by the numpy
+            # twin of the device generator) against the scores the timed steps produced
+            from oracle import ncc_oracle as oracle
+
+            full_h = dev.to_host(full)
+            errs = []
+            for qi in (0, nq - 1):
+                qf = synth.query_features(SEED, qi, int(matches[qi]), C, H, W)
+                for gi in (int(matches[qi]), (int(matches[qi]) + 1) % ng_total):
+                    ref = max(0.0, float(oracle.get_similarity(qf, synth.gallery_features(SEED, gi, C, H, W), precise=True)))
+                    errs.append(abs(ref - float(full_h[qi, gi])))
+            out["parity_sample"] = {"pairs": len(errs), "max_abs_err_vs_oracle": float(f"{max(errs):.3e}"), "tolerance": 1e-4}
     if rank == 0:
         print(json.dumps(out))
     sys.stdout.flush()
