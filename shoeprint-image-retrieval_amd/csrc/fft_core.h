@@ -254,9 +254,16 @@ __device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, c
       }
     }
     wave_sync();  // the image is rewritten by the next phase / the next call
-    if constexpr (E >= TG) Dft<TG, DIR>::run(y[ph]);
+    // Lanes without a sub-transform in this set sit the stage-2 DFT out (exec-masked): their registers keep the
+    // finite values read above.  The kernels run at the board's power limit (~1.4 kW, sclk ~2.0 GHz instead of
+    // 2.4), so work that idle lanes do not do is clock headroom for the others.
+    if constexpr (E >= TG) {
+      if (E % TG == 0 || G::out_valid(t, ph)) Dft<TG, DIR>::run(y[ph]);
+    }
   }
-  if constexpr (E < TG) Dft<TG, DIR>::run(y[0]);
+  if constexpr (E < TG) {
+    if (G::out_valid(t, 0)) Dft<TG, DIR>::run(y[0]);
+  }
 }
 
 }  // namespace spr
