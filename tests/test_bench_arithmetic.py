@@ -1,0 +1,31 @@
+"""The roofline arithmetic bench.py reports must match the figures stated in SURVEY §8d / DESIGN §5."""
+import importlib.util
+import math
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_direct_form_flops_match_the_survey():
+    # conv3_3 of a 512x256 print: cropped 124 x 60 maps, 256 channels -> 15.94 GFLOP per pair
+    assert abs(bench.direct_pair_flops(124, 60, 124, 60) * 256 / 1e9 - 15.94) < 0.01
+    # conv4_3: 60 x 28, 512 channels -> 1.626; conv5_3: 28 x 12, 512 -> 0.065
+    assert abs(bench.direct_pair_flops(60, 28, 60, 28) * 512 / 1e9 - 1.626) < 0.002
+    assert abs(bench.direct_pair_flops(28, 12, 28, 12) * 512 / 1e9 - 0.065) < 0.001
+
+
+def test_fft_form_flops_match_design():
+    per_channel = bench.fft_pair_flops((192, 96), 124, 60, 124)
+    parts = (6 * 49 * 192, 48 * 5 * 192 * math.log2(192), 62 * 5 * 96 * math.log2(96), 2 * 124 * 60)
+    assert abs(per_channel - sum(parts)) < 1e-6
+    assert abs(per_channel * 256 / 1e9 - 0.1579) < 1e-4       # 0.1579 GFLOP per pair
+    assert bench.PEAK_FP32_TFLOPS == 157.3
+
+
+def test_clock_sampler_is_inert_without_a_matching_card():
+    s = bench.ClockSampler("ffff:ff:1f.0")
+    s.start()
+    assert s.stop() is None
