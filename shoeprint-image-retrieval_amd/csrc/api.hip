@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -25,6 +26,18 @@ int check_launch(const char* what) {
     return SPR_ERR_HIP;
   }
   return SPR_OK;
+}
+
+int64_t pair_tiles_per_launch(int pairs_per_tile, int threads) {
+  int64_t t = ((static_cast<int64_t>(1) << 32) - 1) / (static_cast<int64_t>(pairs_per_tile) * threads);
+  const int64_t by_blocks = ((static_cast<int64_t>(1) << 31) - 1) / pairs_per_tile;
+  if (by_blocks < t) t = by_blocks;
+  const char* v = std::getenv("SPR_NCC_MAX_TILES");
+  if (v && *v) {
+    const long long cap = std::atoll(v);
+    if (cap >= 1 && cap < t) t = cap;
+  }
+  return t;
 }
 
 size_t prepared_query_item_bytes(const NccGeom& g, int method) {
@@ -53,7 +66,8 @@ struct spr_ncc_plan {
   spr::cf* tw_h = nullptr;  // device: exp(-2*pi*i*k/nh), k < nh
   spr::cf* tw_w = nullptr;  // device: exp(-2*pi*i*k/nw), k < nw
   unsigned* team_sync = nullptr;  // device: arrival counters of the pair kernel's 8 workgroup teams
-  spr::FftWorkspace ws{nullptr, 0};  // device: scratch of the "big" geometries (maps beyond LDS)
+  spr::FftWorkspace ws{nullptr, 0, nullptr};  // device: scratch of the "big" geometries (maps beyond LDS)
+  float* six_ctab = nullptr;  // device: pre-twist table of the six-wave pair kernel
 };
 
 using namespace spr;
@@ -149,6 +163,21 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
         p->ws.bytes = ws_bytes;
       }
     }
+    if (rc == SPR_OK && p->geom.six) {
+      // pre-twist factors of the six-wave row pass: cot(pi k / nw + pi / 4), k < nw / 2 (ncc_pair6.hip)
+      const int half = p->geom.nw / 2;
+      std::vector<float> host(static_cast<size_t>(half));
+      for (int k = 0; k < half; ++k) {
+        const double x = 3.14159265358979323846 * (static_cast<double>(k) / p->geom.nw + 0.25);
+        host[k] = static_cast<float>(std::cos(x) / std::sin(x));
+      }
+      if (hipMalloc(reinterpret_cast<void**>(&p->six_ctab), sizeof(float) * half) != hipSuccess ||
+          hipMemcpy(p->six_ctab, host.data(), sizeof(float) * half, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("pre-twist table: hipMalloc / hipMemcpy failed");
+        rc = SPR_ERR_HIP;
+      }
+      p->ws.six_ctab = p->six_ctab;
+    }
     if (rc != SPR_OK) { spr_ncc_plan_destroy(p); return rc; }
   }
   *plan_out = p;
@@ -161,6 +190,7 @@ extern "C" void spr_ncc_plan_destroy(spr_ncc_plan* plan) {
   if (plan->tw_w) (void)hipFree(plan->tw_w);
   if (plan->team_sync) (void)hipFree(plan->team_sync);
   if (plan->ws.base) (void)hipFree(plan->ws.base);
+  if (plan->six_ctab) (void)hipFree(plan->six_ctab);
   delete plan;
 }
 

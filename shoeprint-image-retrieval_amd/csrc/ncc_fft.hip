@@ -28,48 +28,11 @@
 #include <cstdlib>
 
 #include "fft_core.h"
+#include "ncc_fft_cfg.h"
 #include "ncc_prep_common.h"
 
 namespace spr {
 namespace {
-
-// EH x TGH: column transforms (length nh), EW x TGW: row transforms (length nw); NT = work-items per
-// workgroup of the PAIR kernel (the prep kernel always runs kThreads and writes the prepared data in the
-// pair kernel's lane order); KWA / RRA: the tuned variant's kept outputs per row sub-transform and row
-// rounds (the general variant keeps everything: KW = TGW, RR = all row pairs of the grid).
-template <int EH_, int TGH_, int EW_, int TGW_, int NT_, int KWA_, int RRA_>
-struct Cfg {
-  static constexpr int EH = EH_, TGH = TGH_, EW = EW_, TGW = TGW_, NT = NT_;
-  using GH = GroupFft<EH, TGH>;
-  using GW = GroupFft<EW, TGW>;
-  static constexpr int NH = EH * TGH, NW = EW * TGW;
-  static constexpr int CPR = NT / TGH;  // columns per column-pass round of the pair kernel
-  static constexpr int PPR = NT / TGW;  // row pairs per row-pass round of the pair kernel
-  static constexpr int COLS = NW / 2;   // columns of the intermediate image (column nw/2 rides in column 0)
-  static constexpr int RC = (COLS + CPR - 1) / CPR;  // column rounds per channel
-  static constexpr int KW_A = KWA_, RR_A = RRA_;
-  static constexpr int KW_B = TGW, RR_B = ((NH + 1) / 2 + PPR - 1) / PPR;
-  static_assert(EH % 2 == 0 && EW % 2 == 0, "register pairs are loaded with 16-byte accesses");
-  static constexpr int xbuf_elems(int threads) {
-    return GH::block_elems(threads) > GW::block_elems(threads) ? GH::block_elems(threads) : GW::block_elems(threads);
-  }
-  // prep kernel: a row group's buffer also stages the NW outputs of its transform for the two-row split
-  // (group stride == TGW (mod 16), as in GroupFft)
-  static constexpr int kRowRaw = GW::kGroupElems > NW ? GW::kGroupElems : NW;
-  static constexpr int kRowGroupElems = kRowRaw + ((TGW % 16) - (kRowRaw % 16) + 16) % 16;
-  static constexpr int prep_xbuf_elems(int threads) {
-    return GH::block_elems(threads) > (threads / TGW) * kRowGroupElems ? GH::block_elems(threads)
-                                                                      : (threads / TGW) * kRowGroupElems;
-  }
-  // Position of spectrum element (column j < COLS, k1) in a channel's prepared data: the pair kernel's
-  // lane (group j % CPR, lane-in-group k1 % TGH) loads registers (2mm, 2mm+1), m = k1 / TGH, of column
-  // round j / CPR with one 16-byte access.
-  static __host__ __device__ constexpr int spec_index(int j, int k1) {
-    return (((j / CPR) * (EH / 2) + (k1 / TGH) / 2) * NT + (j % CPR) * TGH + (k1 % TGH)) * 2 + ((k1 / TGH) & 1);
-  }
-  static constexpr int kNyqOffset = RC * EH * NT;  // column nw/2 follows in natural k1 order
-  static constexpr int kSpecPerChan = kNyqOffset + NH;
-};
 
 // The intermediate image is stored TRANSPOSED: RT[j][n1], column j of the half spectrum, row n1, with a
 // row stride == 8 (mod 32) complex values.  Column transforms then write consecutive values per group with
@@ -129,6 +92,10 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
                  static_cast<size_t>(c) * g.inv_per_chan;
     const int nv = g.nv;
     auto store = [&](int n1, int n2, float v) {
+      if constexpr (C::SIX) {  // the six-wave pair kernel's accumulator order (ncc_fft_cfg.h)
+        inv[C::inv6_index(n1, n2)] = v;
+        return;
+      }
       const int pr = n1 >> 1, ab = n1 & 1;
       const int rr = pr / C::PPR, giw = pr - rr * C::PPR;
       const int p = n2 % C::EW, s = n2 / C::EW;       // output n2 = p + EW*s of the row transform
@@ -211,7 +178,13 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
       group_fft<C::EH, C::TGH, -1>(x, y, t, twr, gbuf);
       if (active) {
         cf wx = cmake(1.0f, 0.0f);
-        if (is_query) wx = tw_w[(cx * j) % C::NW];
+        if (is_query) {
+          wx = tw_w[(cx * j) % C::NW];
+          if (C::SIX && j > 0 && !nyq) {  // pre-twist factor of the six-wave row pass: 1 - i w^j, w = e^(+2 pi i / nw)
+            const cf wj = tw_w[j];        // = conj(w^j) = (cos, -sin)
+            wx = cmul(wx, cmake(1.0f - wj.y, -wj.x));
+          }
+        }
 #pragma unroll
         for (int pp = 0; pp < GH::SPL; ++pp) {
           if (!GH::out_valid(t, pp)) continue;
@@ -223,7 +196,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
               const cf wy = tw_h[(cy * k1) % C::NH];
               v = cmul(cmul(cconj(v), wy), wx);  // conj(A) * w^(cy k1) * w^(cx k2): centre shift folded in
             }
-            spec[nyq ? C::kNyqOffset + k1 : C::spec_index(j, k1)] = v;
+            spec[nyq ? C::kNyqOffset + k1 : C::spec_index(C::slot(j), k1)] = v;
           }
         }
       }
@@ -670,6 +643,7 @@ struct FftEntry {
   size_t (*prep_slot_bytes)(const NccGeom&, bool);
   size_t (*pair_slot_bytes)(const NccGeom&);
   bool big_only;  // grid whose working set never fits LDS: always the workspace ("big") kernels
+  bool six;       // prepared layouts + pair kernel of ncc_pair6.hip (six waves per pair)
 };
 
 // Work-items of the prep kernel: 8 waves where the grid gives them work and their exchange buffers fit
@@ -826,7 +800,22 @@ constexpr FftEntry entry() {
                   C::KW_A, C::RR_A, C::KW_B, C::RR_B, rk_tuned<C>(),
                   (C::NH & (C::NH - 1)) == 0 && (C::NW & (C::NW - 1)) == 0,
                   C::kSpecPerChan, prep_lds_total_t<C>, pair_lds_total_t<C>, prep_t<C>, pair_t<C, PFA>,
-                  prep_slot_bytes_t<C>, pair_slot_bytes_t<C>, BIG_ONLY};
+                  prep_slot_bytes_t<C>, pair_slot_bytes_t<C>, BIG_ONLY, false};
+}
+
+// The six-wave pair kernel lives in ncc_pair6.hip; the prep kernel here writes its layouts (Cfg<..., SIX = 1>).
+size_t pair6_lds_total(const NccGeom&) { return pair6_lds_bytes(); }
+size_t no_slot_bytes(const NccGeom&) { return 0; }
+int pair6_t(const NccGeom& g, bool, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
+            int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf*, unsigned*, const FftWorkspace& ws,
+            hipStream_t stream) {
+  return launch_pair6(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, ws.six_ctab, stream);
+}
+template <class C>
+constexpr FftEntry entry6() {
+  return FftEntry{C::NH, C::NW, C::EH, C::TGH, C::EW, C::TGW, C::NT, C::GW::SPL, 0, 0, 0, 0, 0, false,
+                  C::kSpecPerChan, prep_lds_total_t<C>, pair6_lds_total, prep_t<C>, pair6_t,
+                  prep_slot_bytes_t<C>, no_slot_bytes, false, true};
 }
 
 // (E, TG) factorisations: 256 = 16*16, 192 = 12*16, 128 = 16*8, 96 = 12*8, 64 = 8*8, 32 = 8*4, 16 = 4*4.
@@ -840,6 +829,7 @@ constexpr FftEntry entry() {
 const FftEntry kEntries[] = {
     entry<Cfg<8, 4, 4, 4, 64, 2, 1>, 1>(),
     entry<Cfg<12, 8, 6, 8, 192, 5, 2>, 1>(),
+    entry6<Cfg<12, 16, 12, 8, 384, 5, 2, 1>>(),
     entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),
 };
 #else
@@ -852,6 +842,7 @@ const FftEntry kEntries[] = {
     entry<Cfg<12, 8, 6, 8, 192, 5, 2>, 1>(),      // 96 x 48: conv4_3 maps; 3 waves = its 24 columns x 8 lanes exactly
     entry<Cfg<16, 8, 8, 8, 256, 4, 1>, 1>(),      // 128 x 64
     entry<Cfg<16, 8, 16, 8, 256, 4, 1>, 1>(),     // 128 x 128
+    entry6<Cfg<12, 16, 12, 8, 384, 5, 2, 1>>(),   // 192 x 96 on SIX waves per pair (ncc_pair6.hip): maps up to 126 x 64
     entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),    // 192 x 96: conv3_3 of a 512x256 print; two workgroups per CU
     entry<Cfg<16, 16, 16, 8, 512, 4, 1>, 2>(),    // 256 x 128: 8 waves per workgroup, one workgroup per CU
     entry<Cfg<24, 16, 12, 16, 512, 11, 4>, 1, true>(),  // 384 x 192: maps up to 256 x 128 (conv3_3 of a 1024x512 print,
@@ -859,9 +850,9 @@ const FftEntry kEntries[] = {
 };
 #endif
 
-const FftEntry* find_entry(int nh, int nw) {
+const FftEntry* find_entry(int nh, int nw, int six) {
   for (const FftEntry& e : kEntries)
-    if (e.nh == nh && e.nw == nw) return &e;
+    if (e.nh == nh && e.nw == nw && (e.six ? 1 : 0) == six) return &e;
   return nullptr;
 }
 
@@ -873,7 +864,20 @@ inline int fft_need(int img, int tpl) {
 
 bool fill_geometry(NccGeom& g, const FftEntry& e, bool big) {
   g.big = big ? 1 : 0;
+  g.six = e.six ? 1 : 0;
   g.nh = e.nh; g.nw = e.nw; g.eh = e.eh; g.tgh = e.tgh; g.ew = e.ew; g.tgw = e.tgw; g.nt = e.nt;
+  if (e.six) {
+    // one real-output row transform per image row on three lanes; SPR_NCC_SIX=0 keeps the four-wave kernel (A/B runs)
+    if (big || env_int("SPR_NCC_SIX", 1) == 0) return false;
+    if (g.ih > pair6_max_rows() || g.iw > pair6_max_cols()) return false;
+    g.rounds_c = 2; g.r_rows = g.ih; g.r_stride = 0; g.rounds_r = 1; g.tight = 1; g.keep_w = 0; g.nv = 24;
+    g.spec_per_chan = e.spec_per_chan;
+    g.inv_per_chan = 6 * e.nt * 4;
+    if (g.ih * g.iw > kMaxPixPerThread * kThreads || g.th * g.tw > kMaxPixPerThread * kThreads) return false;
+    if (e.prep_lds_total(g, true) > static_cast<size_t>(kLdsLimit)) return false;
+    if (e.prep_lds_total(g, false) > static_cast<size_t>(kLdsLimit)) return false;
+    return e.pair_lds_total(g) <= static_cast<size_t>(kLdsLimit);
+  }
   const int cpr = e.nt / e.tgh, ppr = e.nt / e.tgw;
   g.rounds_c = ceil_div(e.nw / 2, cpr);
   g.r_rows = (g.ih + 7) / 8 * 8;  // rows kept after the column pass (even; rows >= ih carry 1/sigma = 0)
@@ -932,7 +936,7 @@ bool fft_geometry(NccGeom& g, bool pow2_only) {
 
 size_t fft_workspace_bytes(const NccGeom& g) {
   if (!g.big) return 0;
-  const FftEntry* e = find_entry(g.nh, g.nw);
+  const FftEntry* e = find_entry(g.nh, g.nw, g.six);
   if (!e) return 0;
   const size_t prep_q = e->prep_slot_bytes(g, true), prep_g = e->prep_slot_bytes(g, false);
   const size_t prep = (prep_q > prep_g ? prep_q : prep_g) * static_cast<size_t>(g.channels) * 2;  // two items per launch
@@ -943,7 +947,7 @@ size_t fft_workspace_bytes(const NccGeom& g) {
 int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
                     const cf* tw_w, const FftWorkspace& ws, hipStream_t stream) {
   if (n == 0) return SPR_OK;
-  const FftEntry* e = find_entry(g.nh, g.nw);
+  const FftEntry* e = find_entry(g.nh, g.nw, g.six);
   if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
   return e->prep(g, is_query, maps, n, prepared, tw_h, tw_w, ws, stream);
 }
@@ -952,7 +956,7 @@ int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
                     unsigned* team_sync, const FftWorkspace& ws, hipStream_t stream) {
   if (nq == 0 || ng == 0) return SPR_OK;
-  const FftEntry* e = find_entry(g.nh, g.nw);
+  const FftEntry* e = find_entry(g.nh, g.nw, g.six);
   if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
   return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, team_sync, ws, stream);
 }

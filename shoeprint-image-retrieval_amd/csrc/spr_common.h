@@ -41,6 +41,7 @@ struct NccGeom {
   int nt;              // work-items per workgroup of the pair kernel (prepared layouts are tiled by it)
   int eh, tgh, ew, tgw;
   int big;             // 1: working set in the plan's global workspace instead of LDS (maps too large for LDS)
+  int six;             // 1: prepared layouts of the six-wave pair kernel (ncc_pair6.hip)
   int tight;           // 1: ih <= nh/2 and iw <= nw/2 (the pruned kernel variant), 0: general variant
   int rounds_c;        // column-pass rounds of (kThreads/tgh) columns covering nw/2 columns
   int r_rows;          // rows of the intermediate LDS image kept after the column pass (ih rounded up to 8)
@@ -68,7 +69,17 @@ int launch_pair_direct(const NccGeom& g, const void* pq, int64_t nq, const void*
 struct FftWorkspace {  // the plan's scratch for "big" FFT geometries (null / 0 otherwise)
   void* base;
   size_t bytes;
+  const float* six_ctab;  // six-wave pair kernel: its pre-twist table (nw/2 floats), null otherwise
 };
+// six-wave pair kernel (ncc_pair6.hip)
+size_t pair6_lds_bytes();
+int pair6_max_rows();  // cropped search-map rows / columns it covers
+int pair6_max_cols();
+int launch_pair6(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
+                 int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const float* ctab, hipStream_t stream);
+// Pair kernels run one workgroup per pair in tiles of `pairs_per_tile`; HIP refuses a grid of 2^32 work-items or
+// more, so a launch takes at most this many tiles (SPR_NCC_MAX_TILES lowers it: tests of the slicing).
+int64_t pair_tiles_per_launch(int pairs_per_tile, int threads);
 size_t fft_workspace_bytes(const NccGeom& g);  // what a plan with this geometry must allocate (0: none)
 int launch_prep_fft(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, const cf* tw_h,
                     const cf* tw_w, const FftWorkspace& ws, hipStream_t stream);

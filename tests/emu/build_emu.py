@@ -33,7 +33,7 @@ def build(sanitize: bool | None = None, verbose: bool = False) -> str:
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-I", HERE, "-I", CSRC, "-Wall",
-             "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable"]
+             "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable", "-DSPR_EMU"]
     if sanitize:
         # trap mode: no sanitizer runtime has to be linked into (or preloaded for) the shared object; any
         # undefined behaviour executes a trap instruction and kills the test process

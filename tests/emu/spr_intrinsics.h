@@ -39,12 +39,45 @@ inline float shfl(float v, int src) { return exchange(v, src); }
 inline int shfl(int v, int src) { return exchange(v, src); }
 
 inline int opaque(int v) { return v; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+inline void pin(f32x2&) {}
 
 // soft team barrier: workgroups run one after another here, so the wait is the timeout case (returns at once)
 inline void team_arrive(unsigned* counter, unsigned n) { __atomic_fetch_add(counter, n, __ATOMIC_RELAXED); }
 inline void team_wait(unsigned*, unsigned, int) {}
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// buffer loads: the hardware's range check (lane offset + access size against the descriptor's size, the uniform
+// offset unchecked) returns zeros; here a violation aborts - the kernels never rely on it
+struct BufRsrc {
+  const char* base;
+  size_t bytes;
+};
+inline BufRsrc make_rsrc(const void* base, size_t bytes) { return BufRsrc{static_cast<const char*>(base), bytes}; }
+inline void buf_check(const BufRsrc& r, unsigned lane_off, unsigned n) {
+  if (static_cast<size_t>(lane_off) + n > r.bytes || r.bytes >= (static_cast<size_t>(1) << 32)) {
+    std::fprintf(stderr, "hipemu: buffer load outside its descriptor (lane offset %u + %u > %zu)\n", lane_off, n, r.bytes);
+    std::abort();
+  }
+}
+inline float4 buf_ld16(BufRsrc r, unsigned lane_off, unsigned uniform_off) {
+  buf_check(r, lane_off, 16);
+  float4 v;
+  std::memcpy(&v, r.base + lane_off + uniform_off, 16);
+  return v;
+}
+// barrier of a group of waves on an LDS counter: every work-item spins (yielding to the other fibers)
+inline void group_barrier(unsigned* ctr, unsigned target) {
+  hipemu::yield(hipemu::WAIT_WAVE);  // the wave's earlier LDS traffic is complete
+  if (lane_id() == 0) __atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED);
+  while (static_cast<int>(__atomic_load_n(ctr, __ATOMIC_RELAXED) - target) < 0) hipemu::yield(hipemu::RUN);
+}
+
+inline f32x2 buf_ld8(BufRsrc r, unsigned lane_off, unsigned uniform_off) {
+  buf_check(r, lane_off, 8);
+  f32x2 v;
+  std::memcpy(&v, r.base + lane_off + uniform_off, 8);
+  return v;
+}
 inline f32x2 pk_add_i(f32x2 e, f32x2 o) { return f32x2{e.x - o.y, e.y + o.x}; }
 inline f32x2 pk_sub_i(f32x2 e, f32x2 o) { return f32x2{e.x + o.y, e.y - o.x}; }
 inline f32x2 pk_conj_add_i(f32x2 a, f32x2 b) { return f32x2{a.x + b.y, b.x - a.y}; }
@@ -56,6 +89,24 @@ inline f32x2 pk_rot(f32x2 a, float c, float s) {
   const f32x2 t = {a.x * c, a.y * c};
   return f32x2{std::fmaf(-a.y, s, t.x), std::fmaf(a.x, s, t.y)};
 }
+
+template <int SEL>
+inline f32x2 pk_axpy(f32x2 a, f32x2 kk, f32x2 c) {
+  const float k = SEL ? kk.y : kk.x;
+  return f32x2{std::fmaf(a.x, k, c.x), std::fmaf(a.y, k, c.y)};
+}
+template <int SEL>
+inline f32x2 pk_iaxpy(f32x2 a, f32x2 kk, f32x2 c) {
+  const float k = SEL ? kk.y : kk.x;
+  return f32x2{std::fmaf(-a.y, k, c.x), std::fmaf(a.x, k, c.y)};
+}
+inline f32x2 pk_iaxpy_u(f32x2 a, float k, f32x2 c) { return f32x2{std::fmaf(-a.y, k, c.x), std::fmaf(a.x, k, c.y)}; }
+template <int SEL>
+inline f32x2 pk_conj_iaxpy(f32x2 a, f32x2 kk, f32x2 b) {
+  const float k = SEL ? kk.y : kk.x;
+  return f32x2{std::fmaf(-a.y, k, b.x), std::fmaf(a.x, k, -b.y)};
+}
+inline int uniform(int v) { return v; }
 
 // Emulated MFMA: every lane publishes its A/B element, then computes its own D entries as the
 // k-ordered fmaf chain the hardware produces.

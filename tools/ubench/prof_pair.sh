@@ -1,0 +1,43 @@
+# SQ / TCC counters of the pair kernel alone: prof_pair.sh <tag> [VAR=value ...]  -> gpurun_out/pp_<tag>/summary.txt
+# (own --pmc passes, no trace domains; the program after "--" is python3 itself)
+export TMPDIR=/tmp
+R=$PWD
+TAG=$1; shift
+for kv in "$@"; do export "$kv"; done
+OUT=$R/gpurun_out/pp_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+i=0
+for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVES" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+           "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/p$i -o x -- python3 $R/tools/ubench/one_pair_launch.py > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o x -- python3 $R/tools/ubench/one_pair_launch.py > $OUT/stats.log 2>&1
+python3 - "$OUT" <<'PY' > $OUT/summary.txt
+import collections, csv, glob, os, sys
+d = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(set))
+for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "pair" not in k: continue
+        k = "pair6" if "pair6" in k else "pair_fft"
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+for k in acc:
+    c = {a: acc[k][a] / len(n[k][a]) for a in acc[k]}
+    print(k)
+    for a in sorted(c): print(f"  {a:28s} {c[a]:.4g}")
+    w = c.get("SQ_WAVE_CYCLES", 0)
+    if w:
+        for a in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"):
+            if a in c: print(f"  {a}/WAVE_CYCLES = {c[a]/w:.3f}")
+    if c.get("SQ_LDS_IDX_ACTIVE"): print(f"  bank conflict rate = {c.get('SQ_LDS_BANK_CONFLICT',0)/c['SQ_LDS_IDX_ACTIVE']:.3f}")
+    if "TCC_HIT_sum" in c: print(f"  L2 hit = {c['TCC_HIT_sum']/(c['TCC_HIT_sum']+c['TCC_MISS_sum']):.3f}")
+for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "pair" in r["Name"]: print("stats:", r["Name"][:60], r["Calls"], r["AverageNs"])
+PY
+cat $OUT/summary.txt
