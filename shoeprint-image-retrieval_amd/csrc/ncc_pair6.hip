@@ -31,6 +31,11 @@ namespace {
 
 // -DSPR_STAMPS: diagnostic build only (tools/ubench/stamps_pair6.py): lane 0 of every wave of ONE workgroup records
 // the shader clock at the phase boundaries of eight channels into a buffer nothing else reads.
+// -DSPR_ABL=n: timing ablations (wrong results), tools/ubench/ablate_pair6.sh.  1: no operand loads, 2: no pair
+// barriers, 3: no LDS stores, 4: no 16-point stages, 5: no LDS reads of the exchanges / image
+#ifndef SPR_ABL
+#define SPR_ABL 0
+#endif
 #ifdef SPR_STAMPS
 constexpr int kStampPoints = 12, kStampChannels = 8, kStampFirst = 8;
 __device__ unsigned long long g_stamps[12 * kStampChannels * kStampPoints];
@@ -155,27 +160,31 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
   const cf* qspec = reinterpret_cast<const cf*>(pq + static_cast<size_t>(qi) * q_item_bytes);
   const int last_c = g.channels - 1;
 
-  // ---- prefetch state --------------------------------------------------------------------------------
-  float4 nxt[2 * H2];  // the next column round's operands: H2 x (2 complex of G), H2 x (2 complex of Q)
-  cf nyq_g, nyq_q;  // (every lane loads both sides' value and keeps its own: a select between two resource
-                    // descriptors would put the load into a waterfall loop)
-  // operands stream in through buffer loads: descriptor = one prepared item, lane offset = 16 * lane, the rest
-  // (channel, round, register) is a scalar offset
+  // ---- operand streams ---------------------------------------------------------------------------------
+  // Buffer loads: descriptor = one prepared item, lane offset = 16 * lane of the pair, the rest (channel, column
+  // round, register) is a scalar offset.
+  float4 nxt[2 * H2];  // operands of the next column unit: H2 x (2 complex of G), H2 x (2 complex of Q)
+  cf nyq_g, nyq_q;     // (every lane loads both sides' Nyquist value and keeps its own: a select between two resource
+                       // descriptors would put the load into a waterfall loop)
   const BufRsrc g_rs = make_rsrc(g_item, g_item_bytes), q_rs = make_rsrc(qspec, q_item_bytes);
   const unsigned voff16 = static_cast<unsigned>(tid0) * 16u;
   const unsigned voff_nyq = static_cast<unsigned>(tid0 % C::NH) * 8u + C::kNyqOffset * 8u;
   constexpr unsigned kChanBytes = C::kSpecPerChan * 8u;
   const unsigned inv_base = static_cast<unsigned>(g.channels) * kChanBytes;
-  auto issue_unit = [&](int c, int rc) {
-    c = c > last_c ? last_c : c;  // the one-past-the-end prefetch re-reads the last channel (never used)
+  auto issue_unit = [&](int c, int rc) {  // column round rc of channel c: this wave's four columns
+    c = c > last_c ? last_c : c;          // the prefetches past the last channel re-read it (never used)
     const unsigned so = static_cast<unsigned>(c) * kChanBytes + static_cast<unsigned>(rc * H2 * NT * 16);
+    if (SPR_ABL == 1) {
+      for (int mm = 0; mm < 2 * H2; ++mm) nxt[mm] = make_float4(0.001f * so, 0.5f, 0.25f, 0.125f);
+      return;
+    }
 #pragma unroll
     for (int mm = 0; mm < H2; ++mm) {
       nxt[mm] = buf_ld16(g_rs, voff16, so + mm * NT * 16);
       nxt[H2 + mm] = buf_ld16(q_rs, voff16, so + mm * NT * 16);
     }
   };
-  auto issue_nyq = [&](int c) {  // 2 NH = NT values: lanes [0, NH) the gallery's, [NH, 2 NH) the query's
+  auto issue_nyq = [&](int c) {  // 2 NH = NT values: lanes [0, NH) keep the gallery's, [NH, 2 NH) the query's
     c = c > last_c ? last_c : c;
     const unsigned so = static_cast<unsigned>(c) * kChanBytes;
     nyq_g = buf_ld8(g_rs, voff_nyq, so);
@@ -185,141 +194,158 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
 
 #ifndef SPR_EMU
   {
+    // Static wave priorities.  The SIMD arbitrates by priority, then age, and the twelve waves sit three to a SIMD
+    // in dispatch order: without this the first pair holds the four oldest waves and the second pair the four
+    // youngest, and every workgroup ends with the first pair's SIMD slots idle while the second finishes.
+    // Raising waves 4, 5 and 8-11 gives each pair two waves of each rank (measured: +7 %).
     const int gw = half * 6 + wv;  // wave of the workgroup, in dispatch (= age) order
     int pr = 0;
     if (g.prio_mode == 1) pr = gw >= 8 ? 1 : 0;
     else if (g.prio_mode == 2) pr = (gw == 4 || gw == 5 || gw >= 8) ? 1 : 0;
-    else if (g.prio_mode == 3) pr = gw >= 8 ? 2 : (gw >= 4 ? 1 : 0);
-    else if (g.prio_mode == 4) pr = gw < 4 ? 2 : (gw < 8 ? 1 : 0);
-    else if (g.prio_mode == 5) pr = half;
     if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
   }
 #endif
   cf acc[6][2];
 #pragma unroll
   for (int pp = 0; pp < 6; ++pp) acc[pp][0] = acc[pp][1] = cmake(0.0f, 0.0f);
 
+  // ---- prologue ---------------------------------------------------------------------------------------------------------
   issue_nyq(0);
-  issue_unit(0, 0);
   nyq[tid0] = tid0 < C::NH ? nyq_g : nyq_q;
+  issue_nyq(1);
+  nyq[NT + tid0] = tid0 < C::NH ? nyq_g : nyq_q;
+  issue_unit(0, 0);
   __syncthreads();
+  cf za[12];  // unit A's product spectrum, formed one phase ahead
+  {
+    const int tid = tid0, lane = tid0 & 63, tc = lane & 15;
+    (void)lane;
+#pragma unroll
+    for (int mm = 0; mm < H2; ++mm) {
+      const float4 a = nxt[mm], b = nxt[H2 + mm];
+      za[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
+      za[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
+    }
+    if (tid < 16) {
+#pragma unroll
+      for (int m = 0; m < 12; ++m) za[m] = pk_add_i(za[m], cmul(nyq[tc + 16 * m], nyq[C::NH + tc + 16 * m]));
+    }
+    issue_unit(0, 1);
+  }
 
-  // Synchronisation of the six waves of a pair, per channel c (counter barriers, group_barrier):
-  //   B1(c)  after the column pass - every image column is there - before the row pass reads the image;
-  //   B2(c)  before a wave's first LDS store of channel c+1's column pass: every wave has finished reading the
-  //          image of channel c.  It sits INSIDE round 0 of channel c+1, after the product / 12-point stage / twiddles
-  //          (registers only), so a wave that leaves the row pass early has a sixth of a channel's vector work to do
-  //          before it has to wait.
-  // Channel c+1's Nyquist values are loaded in round 0 of channel c and stored to LDS in round 1, i.e. before B1(c);
-  // wave 0 reads them in round 0 of channel c+1 (after B1(c)), hence the two buffers.
-
+  // The column pass is software-pipelined so that a wave has vector work between issuing LDS reads and needing them:
+  //
+  //   12-point stage of A | B2(c-1) | product of B | exchange A | 12-point stage of B | exchange B | part 2 of A |
+  //   part 2 of B | B1(c) | row pass: image reads, pre-twist, 16-point stage, exchange | product of A(c+1) | 3-point stage
+  //
+  // A, B = this wave's unit of column round 0 / 1.  The six waves of a pair meet twice per channel on a counter in LDS
+  // (group_barrier; the other pair of the workgroup runs at its own pace - s_barrier would march all twelve waves through
+  // the same phase at the same time):
+  //   B1(c)  every image column of channel c is stored - before the row pass reads the image;
+  //   B2(c)  every wave has finished reading the image of channel c - before the first LDS store of channel c+1; it
+  //          sits behind part 1 of A (registers only), so a wave that leaves the row pass early has work before it waits.
+  // Channel c+2's Nyquist values are loaded during channel c and stored to LDS at its end, i.e. before B2(c); the wave
+  // with image column 0 reads them in part 1 of A(c+2), after B1(c+1): two buffers.
   for (int c = 0; c < g.channels; ++c) {
 #ifdef SPR_STAMPS
     unsigned long long st[kStampPoints] = {};
 #endif
     SPR_STAMP(0);
-#ifndef SPR_EMU
-    if (g.prio_mode >= 6) {  // experiment: rotate the priority among the three waves of a SIMD, per channel
-      const int gw = half * 6 + wv;
-      const int pr = g.prio_mode == 6 ? (gw / 4 + c) % 3 : (g.prio_mode == 7 ? (gw / 4 + c / 4) % 3 : (2 - gw / 4 + c) % 3);
-      if (pr == 0) __builtin_amdgcn_s_setprio(0);
-      else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(2);
-    }
-#endif
-    // lane coordinates, re-derived from an opaque copy of the lane id every channel (see spr::opaque)
-    const int tid = opaque(tid0);
-    const int lane = tid & 63;
+      // lane coordinates, re-derived from an opaque copy of the lane id every channel: otherwise the ~20 lane addresses
+      // and constants below are hoisted out of the channel loop and sit in registers through every phase (spr::opaque)
+      const int tid = opaque(tid0);
+      const int lane = tid & 63;
+    const int g4 = lane >> 4, tc = lane & 15;  // column role: group of the wave, lane of the group
+
+    // ---- pieces of the column pass (a UNIT = this wave's four columns of one column round) ---------------------------
+    // part 1, registers only: operands -> product spectrum (two operand registers become one) ...
+    auto product = [&](cf (&z)[12], int c, int rc) {
+  #pragma unroll
+      for (int mm = 0; mm < H2; ++mm) {
+        const float4 a = nxt[mm], b = nxt[H2 + mm];
+        z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
+        z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
+      }
+      if (rc == 0 && tid < 16) {  // image column 0: pack column nw/2 into its imaginary part
+        const cf* nq = nyq + (c & 1) * NT;
+  #pragma unroll
+        for (int m = 0; m < 12; ++m) {
+          const int k1 = tc + 16 * m;
+          z[m] = pk_add_i(z[m], cmul(nq[k1], nq[C::NH + k1]));
+        }
+      }
+    };
+    // ... -> 12-point stage -> twiddles
+    auto stage12 = [&](cf (&z)[12]) {
+      pfa12<+1>(z);
+  #pragma unroll
+      for (int p = 1; p < 12; ++p) z[p] = cmul(z[p], twt_h[p * 16 + tc]);
+    };
+    // exchange: row p of the wave's image holds U[p] of all 64 lanes.  Rows 0..5 in the wave's buffer, rows 6..11 in the
+    // image columns of this unit (written at its end, dead until then); `skew` makes row 6 continue the bank sequence of
+    // rows 0..5.  The reads are ISSUED here and consumed by part 2: whatever the caller puts in between hides them.
+    auto exchange = [&](const cf (&z)[12], cf (&y)[16], int rc) {
+      const int own0 = (rc * 24 + 4 * wv) * RS;
+      const int xb_el = (S::kXbOff - S::kImgOff) / 8 + wv * S::kXbWave;  // the wave's buffer, in elements from R
+      const int skew = ((xb_el + 6 - own0) % 32 + 32) % 32;
+      cf* own = R + own0 + skew;
+      wave_sync();  // every lane has read the previous unit's rows
+      cf* w0 = xb + lane;
+      cf* w1 = own + lane;
+  #pragma unroll
+      for (int p = 0; p < 6; ++p) w0[p * XR] = z[p];
+  #pragma unroll
+      for (int p = 6; p < 12; ++p) w1[(p - 6) * XR] = z[p];
+      wave_sync();
+      // lane tc < 12 owns sub-transform p = tc; the four idle lanes of a group re-read row 0 (finite values)
+      const cf* rd = (tc < 6 ? xb + tc * XR : (tc < 12 ? own + (tc - 6) * XR : xb)) + 16 * g4;
+  #pragma unroll
+      for (int tt = 0; tt < 16; ++tt) y[tt] = rd[tt];
+    };
+    // part 2: 16-point stage of the owned sub-transform, rows tc + 12 s of image slot rc * 24 + 4 wv + g4
+    // (s = 10 reaches past the rows anyone reads: harmless)
+    auto part2 = [&](cf (&y)[16], int rc) {
+      wave_sync();  // (every lane has its row before the image stores below overwrite rows 6..11 of the exchange)
+      if (tc < 12) {
+        Dft<16, +1>::run(y);
+        cf* col = R + (rc * 24 + 4 * wv + g4) * RS + tc;
+  #pragma unroll
+        for (int s = 0; s < 11; ++s) col[12 * s] = y[s];
+      }
+    };
+
     // =================================== column pass ===================================
     {
-      const int g4 = lane >> 4, tc = lane & 15;
+      cf ya[16], zb[12], yb[16];
+      issue_nyq(c + 2);
+      stage12(za);  // (unit A's product was formed at the end of the previous row pass / in the prologue)
 #pragma unroll
-      for (int rc = 0; rc < 2; ++rc) {
-        cf z[12], y[16];
-#pragma unroll
-        for (int mm = 0; mm < H2; ++mm) {
-          const float4 a = nxt[mm], b = nxt[H2 + mm];
-          z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
-          z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
-        }
-        // operands of the next round start flying now
-        if (rc == 0) {
-          issue_nyq(c + 1);
-          issue_unit(c, 1);
-          SPR_STAMP(1);
-        } else {
-          issue_unit(c + 1, 0);
-          nyq[((c + 1) & 1) * NT + tid] = tid < C::NH ? nyq_g : nyq_q;  // (loaded a round ago)
-          SPR_STAMP(6);
-        }
-        if (rc == 0 && tid < 16) {  // image column 0: pack column nw/2 into its imaginary part
-          const cf* nq = nyq + (c & 1) * NT;
-#pragma unroll
-          for (int m = 0; m < 12; ++m) {
-            const int k1 = tc + 16 * m;
-            z[m] = pk_add_i(z[m], cmul(nq[k1], nq[C::NH + k1]));
-          }
-        }
-        pfa12<+1>(z);
-#pragma unroll
-        for (int p = 1; p < 12; ++p) z[p] = cmul(z[p], twt_h[p * 16 + tc]);
-        if (rc == 0) {
-          // B2 of the previous channel (see above).  The values are pinned in registers first: the compiler would
-          // otherwise sink the arithmetic below the wait.
-#pragma unroll
-          for (int p = 0; p < 12; ++p) pin(z[p]);
-          SPR_STAMP(2);
-          bar_target += S::WAVES;
-          group_barrier(bar, bar_target);
-          SPR_STAMP(3);
-        }
-        // exchange image of the wave: row p holds U[p] of all 64 lanes.  Rows 0..5 in the wave's buffer, rows
-        // 6..11 in the image columns this wave writes at the end of the round (dead until then); `skew` makes
-        // row 6 continue the bank sequence of rows 0..5.
-        const int own0 = (rc * 24 + 4 * wv) * RS;
-        const int xb_el = (S::kXbOff - S::kImgOff) / 8 + wv * S::kXbWave;  // the wave's buffer, in elements from R
-        const int skew = ((xb_el + 6 - own0) % 32 + 32) % 32;
-        cf* own = R + own0 + skew;
-        {
-          cf* w0 = xb + lane;
-          cf* w1 = own + lane;
-#pragma unroll
-          for (int p = 0; p < 6; ++p) w0[p * XR] = z[p];
-#pragma unroll
-          for (int p = 6; p < 12; ++p) w1[(p - 6) * XR] = z[p];
-        }
-        if (rc == 0) { SPR_STAMP(4); }
-        wave_sync();
-        {
-          // lane tc < 12 owns sub-transform p = tc; the four idle lanes of a group re-read row 0 (finite values)
-          const cf* rd = (tc < 6 ? xb + tc * XR : (tc < 12 ? own + (tc - 6) * XR : xb)) + 16 * g4;
-#pragma unroll
-          for (int tt = 0; tt < 16; ++tt) y[tt] = rd[tt];
-        }
-        wave_sync();  // every lane has its row before the image stores below / the next round reuse the rows
-        if (tc < 12) {
-          Dft<16, +1>::run(y);
-          // rows tc + 12 s of image slot rc*24 + 4 wv + g4 (s = 10 reaches past the rows anyone reads: harmless)
-          cf* col = R + (rc * 24 + 4 * wv + g4) * RS + tc;
-#pragma unroll
-          for (int s = 0; s < 11; ++s) col[12 * s] = y[s];
-        }
-        if (rc == 0) { SPR_STAMP(5); } else { SPR_STAMP(7); }
-      }
+      for (int p = 0; p < 12; ++p) pin(za[p]);  // (or the compiler sinks the arithmetic below the wait)
+      SPR_STAMP(1);
+      bar_target += S::WAVES;
+      if (SPR_ABL != 2) group_barrier(bar, bar_target);  // B2(c-1)
+      SPR_STAMP(2);
+      product(zb, c, 1);  // before A's exchange: its 16 reads then overlap 24 live registers, not 48
+      sched_fence();
+      exchange(za, ya, 0);
+      sched_fence();
+      stage12(zb);        // hides exchange A
+      sched_fence();
+      SPR_STAMP(3);
+      exchange(zb, yb, 1);
+      sched_fence();
+      part2(ya, 0);       // hides exchange B
+      sched_fence();
+      SPR_STAMP(4);
+      issue_unit(c + 1, 0);  // consumed in the row pass
+      part2(yb, 1);
+      SPR_STAMP(6);
     }
-    // the six waves of this pair meet; the other pair of the workgroup runs at its own pace (s_barrier would
-    // march all twelve waves through the same phase at the same time: bursts on one pipe, the others idle)
     bar_target += S::WAVES;
-    group_barrier(bar, bar_target);  // B1
-    SPR_STAMP(8);
+    if (SPR_ABL != 2) group_barrier(bar, bar_target);  // B1(c)
+    SPR_STAMP(7);
     // =================================== row pass ===================================
     {
-      float4 iv[6];
-      const unsigned so_inv = inv_base + static_cast<unsigned>(c) * static_cast<unsigned>(g.inv_per_chan) * 4u;
-#pragma unroll
-      for (int pp = 0; pp < 6; ++pp) iv[pp] = buf_ld16(g_rs, voff16, so_inv + pp * NT * 16);
-
       const int grp = lane / 3;
       const int t3 = lane - 3 * grp;
       // (lane 63 has no row group and shadows group 20.  Rows >= ih: every row below 132 is written by the column
@@ -338,8 +364,8 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
         for (int h = 0; h < 2; ++h) {
           const int a = 2 * a2 + h;
           const int ra = (3 * a) % 16, rm = (3 * ((16 - a) % 16)) % 16;
-          const cf av = dbase[3 * ra * RS];
-          const cf bv = mbase[3 * rm * RS];
+          const cf av = SPR_ABL == 5 ? cmake(0.5f * a, ck.x) : dbase[3 * ra * RS];
+          const cf bv = SPR_ABL == 5 ? cmake(ck.y, 0.25f * a) : mbase[3 * rm * RS];
           cf v = h == 0 ? pk_conj_iaxpy<0>(av, ck, bv) : pk_conj_iaxpy<1>(av, ck, bv);
           if (a == 0) {  // k = 0 (lane 0 of the group): image slot 0 holds (Y[0], Y[nw/2]), both real
             const cf v0 = cmake(av.x + av.y, av.x - av.y);
@@ -348,8 +374,15 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
           z[a] = v;
         }
       }
-      SPR_STAMP(9);
-      Dft<16, +1>::run(z);
+      SPR_STAMP(8);
+      if (SPR_ABL != 4) Dft<16, +1>::run(z);
+      sched_fence();
+      // the 1/sigma slice is needed at the very end: requested only now, it does not sit in registers during the
+      // 16-point stage (the exchange below is what hides its latency)
+      float4 iv[6];
+      const unsigned so_inv = inv_base + static_cast<unsigned>(c) * static_cast<unsigned>(g.inv_per_chan) * 4u;
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) iv[pp] = SPR_ABL == 1 ? make_float4(1.f, 1.f, 1.f, 1.f) : buf_ld16(g_rs, voff16, so_inv + pp * NT * 16);
       // 3-point lane stage.  The exchange image (16 rows of 64 lanes) lies in the image rows this wave has just
       // consumed - rows 21 wv .. 21 wv + 20 of all 48 slots, which no other wave reads: exchange row r takes slots
       // 3r .. 3r+2 (21 lanes each, a row group never straddles two) - so all 16 values leave in one burst and
@@ -361,18 +394,21 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       const cf* rx = R + (grp_r / 7) * RS + wv * C::kRowGroups + 3 * (grp_r % 7) + 3 * t3 * RS;
       const cf* rx15 = R + (grp_r / 7) * RS + wv * C::kRowGroups + 3 * (grp_r % 7) + 45 * RS;
       wave_sync();  // every lane of the wave has read its image rows
-      if (lane < 63) {
+      if (lane < 63 && SPR_ABL != 3) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) wx[3 * r * RS] = z[r];
       }
-      SPR_STAMP(10);
+      SPR_STAMP(9);
       wave_sync();
       cf yv[6][3];
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)  // row n1 = t3 + 3 pp; rows 16, 17 do not exist: those lanes re-read row 15
-          yv[pp][tt] = pp < 5 ? rx[9 * pp * RS + tt] : rx15[tt];
+          yv[pp][tt] = SPR_ABL == 5 ? z[(3 * pp + tt) % 16] : (pp < 5 ? rx[9 * pp * RS + tt] : rx15[tt]);
+      sched_fence();
+      product(za, c + 1, 0);  // the next channel's unit A (operands requested during the column pass): hides the reads
+      sched_fence();
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) {
         const cf y0 = yv[pp][0], y1 = yv[pp][1], y2 = yv[pp][2];
@@ -396,8 +432,10 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
           }
         }
       }
+      issue_unit(c + 1, 1);  // unit B of the next channel: consumed behind B2
+      nyq[(c & 1) * NT + tid] = tid < C::NH ? nyq_g : nyq_q;  // channel c + 2's
     }
-    SPR_STAMP(11);
+    SPR_STAMP(10);
 #ifdef SPR_STAMPS
     if (blockIdx.x == 777 && (tid0 & 63) == 0 && c >= kStampFirst && c < kStampFirst + kStampChannels) {
       for (int i = 0; i < kStampPoints; ++i)

@@ -40,6 +40,10 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// The instruction scheduler may not move anything across this point (software-pipelined loops: keeps LDS reads
+// issued where the source issues them, ahead of the arithmetic that is meant to hide them).
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // Pin a value in its vector registers at this point of the program (the compiler may not move its computation below).
 __device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
 

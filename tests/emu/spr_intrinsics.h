@@ -41,6 +41,7 @@ inline int shfl(int v, int src) { return exchange(v, src); }
 inline int opaque(int v) { return v; }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 inline void pin(f32x2&) {}
+inline void sched_fence() {}
 
 // soft team barrier: workgroups run one after another here, so the wait is the timeout case (returns at once)
 inline void team_arrive(unsigned* counter, unsigned n) { __atomic_fetch_add(counter, n, __ATOMIC_RELAXED); }
