@@ -140,6 +140,11 @@ int spr_rank_count_greater(const float* scores, int64_t ld, int64_t n_queries, i
                            int64_t global_col0, const float* match_scores, const int32_t* match,
                            int32_t* counts, spr_stream_t stream);
 
+/* dst[i] = keep * dst[i] + weight * src[i] over n float32 score-matrix elements (keep = 0: dst is only written).
+ * The reference scores ONE feature layer (run.py:20); a multi-layer score (BASELINE config 5: mean of the conv3_3,
+ * conv4_3 and conv5_3 similarities, build-defined) is fused with this on the device. */
+int spr_scores_fuse(float* dst, const float* src, int64_t n, float keep, float weight, spr_stream_t stream);
+
 /* ------------------------------------------------------------------ query variants (rotation / scale)
  * similarity.py:230-284 pushes every query feature map through Pillow: Image.rotate(angle) (NEAREST, no
  * expand, zero fill) or Image.resize((int(w*s), int(h*s))) (BICUBIC on mode "F").  These two entry

@@ -55,6 +55,7 @@ SIGNATURES = {
     "spr_ncc_maps": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "spr_rank_true_match": (C.c_int, [_VP, _I64, _I64, _I64, _VP, _VP, _VP]),
     "spr_rank_count_greater": (C.c_int, [_VP, _I64, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
+    "spr_scores_fuse": (C.c_int, [_VP, _VP, _I64, C.c_float, C.c_float, _VP]),
     "spr_rotate_nearest": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(_I64), _VP]),
     "spr_resample_axis": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "spr_clahe_workspace_bytes": (_SZ, [_I64, _I32, _I32]),

@@ -209,13 +209,21 @@ static int launch_pair_direct_t(const NccGeom& g, const void* pq, int64_t nq, co
   const DirectLds l = direct_lds(g);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_direct_kernel<SPT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_direct_kernel<SPT>), dim3(static_cast<unsigned>(ng), static_cast<unsigned>(nq)),
-                     dim3(kThreads), l.total, stream, g, static_cast<const float*>(pq),
-                     prepared_query_item_bytes(g, SPR_NCC_DIRECT) / sizeof(float), static_cast<const float*>(pg),
-                     prepared_gallery_item_bytes(g, SPR_NCC_DIRECT) / sizeof(float), scores,
-                     static_cast<long long>(ld), static_cast<long long>(col0), accumulate, maps_out, l.pws, l.tws,
-                     static_cast<unsigned>(l.t_off));
-  return check_launch("pair_direct_kernel");
+  // grid = (gallery, query) workgroups; HIP refuses 2^32 work-items and more along x: slices of the gallery
+  const size_t g_item_floats = prepared_gallery_item_bytes(g, SPR_NCC_DIRECT) / sizeof(float);
+  const int64_t max_g = pair_tiles_per_launch(1, kThreads);
+  for (int64_t g0 = 0; g0 < ng; g0 += max_g) {
+    const int64_t n = ng - g0 < max_g ? ng - g0 : max_g;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_direct_kernel<SPT>), dim3(static_cast<unsigned>(n), static_cast<unsigned>(nq)),
+                       dim3(kThreads), l.total, stream, g, static_cast<const float*>(pq),
+                       prepared_query_item_bytes(g, SPR_NCC_DIRECT) / sizeof(float),
+                       static_cast<const float*>(pg) + static_cast<size_t>(g0) * g_item_floats, g_item_floats, scores,
+                       static_cast<long long>(ld), static_cast<long long>(col0 + g0), accumulate, maps_out, l.pws, l.tws,
+                       static_cast<unsigned>(l.t_off));
+    const int rc = check_launch("pair_direct_kernel");
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
 }
 
 int launch_pair_direct(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,

@@ -237,6 +237,7 @@ struct PairArgs {
   int rounds_r;      // row rounds actually needed (<= RR)
   int inv_per_chan;  // floats of 1/sigma per channel
   int accumulate;
+  int tile0;         // tile mode: first 16 x 16 pair tile of this launch (launches are sliced: HIP's grid limit)
   // team mode (team_size > 0): persistent grid of 8 teams (one per XCD) x team_size resident workgroups
   int team_size;     // workgroups per team = pairs per epoch
   int strip_q;       // queries per strip (the last strip may hold fewer)
@@ -380,8 +381,8 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     __syncthreads();
   } else {
     const int tiles_g = ceil_div(ng, kTileG);
-    const int tile = static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
-    const int within = static_cast<int>(blockIdx.x) - tile * (kTileQ * kTileG);
+    const int tile = g.tile0 + static_cast<int>(blockIdx.x) / (kTileQ * kTileG);
+    const int within = static_cast<int>(blockIdx.x) % (kTileQ * kTileG);
     const int tq = tile / tiles_g, tg = tile - tq * tiles_g;
     const int xcd = within & 7, slot = within >> 3;  // 8 XCD groups x 32 slots
     qi = tq * kTileQ + (slot >> 1);
@@ -722,7 +723,7 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
   a.inv_per_chan = g.inv_per_chan; a.accumulate = accumulate;
   const void* kernel = reinterpret_cast<const void*>(pair_fft_kernel<C, RR, KW, PF, RK, BIG, TEAM>);
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  unsigned grid = static_cast<unsigned>(tiles * kTileQ * kTileG);
+  unsigned grid = 0;
   // ---- team mode: a persistent grid that exactly fills the device, 8 teams of co-resident workgroups ----
   int per_cu = 0, cus = 0, dev = 0;
   if (TEAM && !team_sync) { set_error("pair_fft_kernel: the team schedule needs the plan's counters"); return SPR_ERR_ARG; }
@@ -756,15 +757,27 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
     }
   }
   if (TEAM && a.team_size == 0) { set_error("pair_fft_kernel: could not size the persistent grid"); return SPR_ERR_HIP; }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK, BIG, TEAM>), dim3(grid),
-                     dim3(C::NT), l.total, stream, a, static_cast<const unsigned char*>(pq),
-                     prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
-                     prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores,
-                     static_cast<long long>(ld), static_cast<long long>(col0), maps_out, tw_h, tw_w,
-                     static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off),
-                     static_cast<unsigned>(l.nyq_off), team_sync, static_cast<unsigned char*>(ws.base), l.slot_bytes);
+  // tile mode: HIP refuses grids of 2^32 work-items and more (65 536 tiles of 256-lane workgroups, e.g. 256 queries
+  // against a 65 535-item gallery chunk of small maps), so a launch takes a slice of the tiles
+  const int64_t max_tiles = TEAM ? tiles : pair_tiles_per_launch(kTileQ * kTileG, C::NT);
+  for (int64_t t0 = 0; t0 < (TEAM ? 1 : tiles); t0 += max_tiles) {
+    if (!TEAM) {
+      const int64_t n = tiles - t0 < max_tiles ? tiles - t0 : max_tiles;
+      a.tile0 = static_cast<int>(t0);
+      grid = static_cast<unsigned>(n * kTileQ * kTileG);
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_fft_kernel<C, RR, KW, PF, RK, BIG, TEAM>), dim3(grid),
+                       dim3(C::NT), l.total, stream, a, static_cast<const unsigned char*>(pq),
+                       prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
+                       prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores,
+                       static_cast<long long>(ld), static_cast<long long>(col0), maps_out, tw_h, tw_w,
+                       static_cast<unsigned>(l.r_off), static_cast<unsigned>(l.xbuf_off),
+                       static_cast<unsigned>(l.nyq_off), team_sync, static_cast<unsigned char*>(ws.base), l.slot_bytes);
+    const int rc = check_launch("pair_fft_kernel");
+    if (rc != SPR_OK) return rc;
+  }
   (void)kernel;
-  return check_launch("pair_fft_kernel");
+  return SPR_OK;
 }
 
 // tuned variant: KW_A x RR_A with PFA prefetch buffers; general variant: everything kept, one buffer

@@ -36,6 +36,9 @@ namespace {
 #ifndef SPR_ABL
 #define SPR_ABL 0
 #endif
+#ifndef SPR_P6_PIPE
+#define SPR_P6_PIPE 1
+#endif
 #ifdef SPR_STAMPS
 constexpr int kStampPoints = 12, kStampChannels = 8, kStampFirst = 8;
 __device__ unsigned long long g_stamps[12 * kStampChannels * kStampPoints];
@@ -217,6 +220,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
   issue_unit(0, 0);
   __syncthreads();
   cf za[12];  // unit A's product spectrum, formed one phase ahead
+#if SPR_P6_PIPE != 1
   {
     const int tid = tid0, lane = tid0 & 63, tc = lane & 15;
     (void)lane;
@@ -232,6 +236,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
     }
     issue_unit(0, 1);
   }
+#endif
 
   // The column pass is software-pipelined so that a wave has vector work between issuing LDS reads and needing them:
   //
@@ -318,7 +323,11 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
     {
       cf ya[16], zb[12], yb[16];
       issue_nyq(c + 2);
-      stage12(za);  // (unit A's product was formed at the end of the previous row pass / in the prologue)
+#if SPR_P6_PIPE == 1
+      product(za, c, 0);
+      issue_unit(c, 1);
+#endif
+      stage12(za);  // (pipe 2: unit A's product was formed at the end of the previous row pass / in the prologue)
 #pragma unroll
       for (int p = 0; p < 12; ++p) pin(za[p]);  // (or the compiler sinks the arithmetic below the wait)
       SPR_STAMP(1);
@@ -332,6 +341,12 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       stage12(zb);        // hides exchange A
       sched_fence();
       SPR_STAMP(3);
+#if SPR_P6_PIPE == 1
+      issue_unit(c + 1, 0);
+      part2(ya, 0);
+      exchange(zb, yb, 1);
+      part2(yb, 1);
+#else
       exchange(zb, yb, 1);
       sched_fence();
       part2(ya, 0);       // hides exchange B
@@ -339,6 +354,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       SPR_STAMP(4);
       issue_unit(c + 1, 0);  // consumed in the row pass
       part2(yb, 1);
+#endif
       SPR_STAMP(6);
     }
     bar_target += S::WAVES;
@@ -407,8 +423,10 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
         for (int tt = 0; tt < 3; ++tt)  // row n1 = t3 + 3 pp; rows 16, 17 do not exist: those lanes re-read row 15
           yv[pp][tt] = SPR_ABL == 5 ? z[(3 * pp + tt) % 16] : (pp < 5 ? rx[9 * pp * RS + tt] : rx15[tt]);
       sched_fence();
+#if SPR_P6_PIPE != 1
       product(za, c + 1, 0);  // the next channel's unit A (operands requested during the column pass): hides the reads
       sched_fence();
+#endif
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) {
         const cf y0 = yv[pp][0], y1 = yv[pp][1], y2 = yv[pp][2];
@@ -432,7 +450,9 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
           }
         }
       }
+#if SPR_P6_PIPE != 1
       issue_unit(c + 1, 1);  // unit B of the next channel: consumed behind B2
+#endif
       nyq[(c & 1) * NT + tid] = tid < C::NH ? nyq_g : nyq_q;  // channel c + 2's
     }
     SPR_STAMP(10);

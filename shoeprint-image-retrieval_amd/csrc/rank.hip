@@ -48,8 +48,28 @@ rank_kernel(const float* __restrict__ scores, long long ld, long long n_local, l
   if (tid == 0) out[q] = cnt + (final_rank ? 1 : 0);
 }
 
+// dst[i] = dst[i] * keep + src[i] * weight: the layer fusion of a multi-layer score (build-defined mean of per-layer
+// similarities), on the device so that no layer's matrix travels to the host.  HBM-bound, 12 bytes per element.
+__global__ void __launch_bounds__(kThreads)
+scores_fuse_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, float keep, float weight) {
+  const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i < n) dst[i] = keep == 0.0f ? src[i] * weight : fmaf(dst[i], keep, src[i] * weight);
+}
+
 }  // namespace
 }  // namespace spr
+
+extern "C" int spr_scores_fuse(float* dst, const float* src, int64_t n, float keep, float weight, spr_stream_t stream) {
+  using namespace spr;
+  if (n < 0) { set_error("spr_scores_fuse: bad size"); return SPR_ERR_ARG; }
+  if (n == 0) return SPR_OK;
+  if (!dst || !src) { set_error("spr_scores_fuse: null pointer"); return SPR_ERR_ARG; }
+  const long long blocks = (n + kThreads - 1) / kThreads;
+  if (blocks > 0x7fffffffLL) { set_error("spr_scores_fuse: matrix too large for one call"); return SPR_ERR_ARG; }
+  hipLaunchKernelGGL(scores_fuse_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), dst, src, static_cast<long long>(n), keep, weight);
+  return check_launch("scores_fuse_kernel");
+}
 
 extern "C" int spr_rank_true_match(const float* scores, int64_t ld, int64_t n_queries, int64_t n_gallery,
                                    const int32_t* match, int32_t* ranks, spr_stream_t stream) {

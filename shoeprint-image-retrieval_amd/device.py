@@ -59,6 +59,11 @@ class TorchDevice:
             out[k].copy_(self.torch.from_numpy(np.ascontiguousarray(it, dtype=np.float32)))
         return out
 
+    def astype_storage(self, buf, storage: str):
+        """The float32 batch in its HBM storage type ("float32" | "float16" | "bfloat16"); the kernels read all three."""
+        t = {"float32": self.torch.float32, "float16": self.torch.float16, "bfloat16": self.torch.bfloat16}[storage]
+        return buf if buf.dtype == t else buf.to(t)
+
     def to_host(self, buf) -> np.ndarray:
         return buf.detach().cpu().numpy()
 

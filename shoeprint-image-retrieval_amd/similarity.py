@@ -92,10 +92,12 @@ class NccScorer:
     method : "auto" | "fft" | "direct"  (pair-kernel choice, see the C header)
     max_prepared_bytes: HBM budget for the prepared form of one gallery chunk (default: a third
         of the free memory, at most 64 GiB); larger galleries are processed chunk by chunk.
+    storage: HBM storage type of feature batches uploaded from host lists ("float32" | "float16" | "bfloat16");
+        arithmetic is float32 / float64 whatever the storage.
     """
 
     def __init__(self, device=None, library: _lib.Library | None = None, method: str = "auto",
-                 max_prepared_bytes: int | None = None, crop: int = CROP):
+                 max_prepared_bytes: int | None = None, crop: int = CROP, storage: str = "float32"):
         self.lib = library or _lib.load_library()
         if device is None:
             from .device import TorchDevice
@@ -105,7 +107,11 @@ class NccScorer:
         self.method = _METHODS[method]
         self.crop = crop
         self.max_prepared_bytes = max_prepared_bytes
+        if storage not in ("float32", "float16", "bfloat16"):
+            raise ValueError(f"unknown storage type {storage!r}")
+        self.storage = storage
         self._plans: dict[tuple, _Plan] = {}
+        self._variants = None
 
     # ------------------------------------------------------------------ plans
     def plan(self, channels: int, q_hw, g_hw, dtype=np.float32, crop: int | None = None) -> _Plan:
@@ -225,44 +231,69 @@ class NccScorer:
         g_groups = _group_by_shape(g_items)
         from .variants import VariantBuilder
 
-        builder = VariantBuilder(self.lib, self.dev)
+        if self._variants is None:
+            self._variants = VariantBuilder(self.lib, self.dev)  # (keeps its resample tables on the device)
+        builder = self._variants
+        # Every query shape group is uploaded and expanded into its variant list ONCE; every gallery chunk is uploaded
+        # ONCE and prepared once per plan (= per distinct variant shape: the 1/sigma map depends on the template size).
+        q_side = {}
         for qshape, q_idx in q_groups.items():
             q_batch = self.dev.stack_to_device([q_items[i] for i in q_idx])
-            variants = builder.variants(q_batch, rotations, scales)
             by_shape: dict[tuple, list] = {}  # variants of one shape share a plan and the prepared gallery
-            for v in variants:
-                by_shape.setdefault(tuple(self.dev.shape(v)[2:]), []).append(v)
-            for gshape, g_idx in g_groups.items():
+            for v in builder.variants(q_batch, rotations, scales):
+                by_shape.setdefault(tuple(self.dev.shape(v)[2:]), []).append(self.dev.astype_storage(v, self.storage))
+            q_side[qshape] = by_shape
+        for gshape, g_idx in g_groups.items():
+            plans = {}
+            for qshape, by_shape in q_side.items():
                 if qshape[0] != gshape[0]:
                     raise ValueError(f"channel mismatch: query {qshape}, gallery {gshape}")
-                plans = {vs: self.plan(qshape[0], vs, gshape[1:]) for vs in by_shape}
-                chunk = min(self.gallery_chunk_items(p, len(g_idx)) for p in plans.values())
-                for start in range(0, len(g_idx), chunk):
-                    idx = g_idx[start:start + chunk]
-                    g_batch = self.dev.stack_to_device([g_items[i] for i in idx])
+                for vs in by_shape:
+                    plans[vs] = self.plan(qshape[0], vs, gshape[1:], dtype=self.storage)
+            chunk = min(self.gallery_chunk_items(p, len(g_idx)) for p in plans.values())
+            for start in range(0, len(g_idx), chunk):
+                idx = g_idx[start:start + chunk]
+                g_batch = self.dev.astype_storage(self.dev.stack_to_device([g_items[i] for i in idx]), self.storage)
+                prepared = {}  # plan -> prepared gallery chunk
+                for qshape, q_idx in q_groups.items():
                     sub = self.dev.zeros((len(q_idx), len(idx)), np.float32)
-                    for vs, vlist in by_shape.items():
+                    for vs, vlist in q_side[qshape].items():
                         plan = plans[vs]
-                        pg = self.prepare_gallery(plan, g_batch)
+                        if vs not in prepared:
+                            prepared[vs] = self.prepare_gallery(plan, g_batch)
                         for v in vlist:
                             pq = self.prepare_queries(plan, v)
-                            self.score_prepared(plan, pq, len(q_idx), pg, len(idx), sub, len(idx), 0, accumulate_max=True)
+                            self.score_prepared(plan, pq, len(q_idx), prepared[vs], len(idx), sub, len(idx), 0,
+                                                accumulate_max=True)
                     sub_h = self.dev.to_host(sub)
                     block = out[np.ix_(q_idx, idx)]
                     out[np.ix_(q_idx, idx)] = np.maximum(block, sub_h)
         return out
 
-    def multi_layer_score_matrix(self, layers) -> np.ndarray:
-        """Mean over feature layers of the per-layer [Q,G] matrices (e.g. conv3_3 +
-        conv4_3 + conv5_3 maps of the same items; build-defined, the reference scores one layer).
-        ``layers`` = [(q_dev [Q,C_l,h_l,w_l], g_dev [G,C_l,h_l,w_l]), ...] resident in HBM."""
-        total = None
-        for q_dev, g_dev in layers:
-            s = self.dev.to_host(self.scores_device(q_dev, g_dev))
-            total = s.astype(np.float32) if total is None else total + s
-        if total is None:
+    def multi_layer_scores_device(self, layers, out=None):
+        """Device [Q,G] float32 mean over feature layers of the per-layer score matrices (e.g.
+        conv3_3 + conv4_3 + conv5_3 maps of the same items; build-defined, the reference scores one layer).
+        ``layers`` = [(q_dev [Q,C_l,h_l,w_l], g_dev [G,C_l,h_l,w_l]), ...] resident in HBM.  Nothing leaves the
+        device: each layer's matrix is folded into the running mean by spr_scores_fuse."""
+        layers = list(layers)
+        if not layers:
             raise ValueError("no feature layers given")
-        return total / np.float32(len(layers))
+        weight = 1.0 / len(layers)
+        layer_scores = None
+        for k, (q_dev, g_dev) in enumerate(layers):
+            nq, ng = self.dev.shape(q_dev)[0], self.dev.shape(g_dev)[0]
+            if out is None:
+                out = self.dev.zeros((nq, ng), np.float32)
+            if layer_scores is None:
+                layer_scores = self.dev.zeros((nq, ng), np.float32)
+            self.scores_device(q_dev, g_dev, scores=layer_scores)
+            self.lib.check(self.lib.spr_scores_fuse(self.dev.ptr(out), self.dev.ptr(layer_scores), nq * ng,
+                                                    0.0 if k == 0 else 1.0, weight, self.dev.stream()))
+        return out
+
+    def multi_layer_score_matrix(self, layers) -> np.ndarray:
+        """Host copy of multi_layer_scores_device (one transfer, of the fused matrix)."""
+        return self.dev.to_host(self.multi_layer_scores_device(layers))
 
     def ranks(self, scores_host: np.ndarray, matching_pairs: Sequence[int]) -> np.ndarray:
         nq, ng = scores_host.shape
@@ -299,6 +330,28 @@ def default_scorer() -> NccScorer:
     return _default_scorer
 
 
+_config_scorers: dict[tuple, NccScorer] = {}
+
+
+def scorer_from_config(config: dict, *, device=None, library: _lib.Library | None = None) -> NccScorer:
+    """The scorer that ``[mi355x]`` of run.toml asks for: ``ncc_method`` ("auto" | "fft" | "fft_pow2" | "direct"),
+    ``dtype`` (HBM storage type of the feature maps: "float32" | "float16" | "bfloat16") and ``max_prepared_gib`` (HBM
+    budget of one prepared gallery chunk; 0 = automatic).  Reference files, which have no such table, get the defaults."""
+    extra = config.get("mi355x") or {}
+    method = extra.get("ncc_method", "auto") or "auto"
+    storage = extra.get("dtype", "float32") or "float32"
+    gib = float(extra.get("max_prepared_gib", 0.0) or 0.0)
+    if method not in _METHODS:
+        raise ValueError(f"[mi355x].ncc_method = {method!r}: expected one of {sorted(_METHODS)}")
+    key = (method, storage, gib, id(device), id(library))
+    if key == ("auto", "float32", 0.0, id(None), id(None)):
+        return default_scorer()
+    if key not in _config_scorers:
+        _config_scorers[key] = NccScorer(device=device, library=library, method=method, storage=storage,
+                                         max_prepared_bytes=int(gib * (1 << 30)) if gib > 0 else None)
+    return _config_scorers[key]
+
+
 def compare_maps(
     shoemark_maps: list[np.ndarray],
     shoeprint_maps: list[np.ndarray],
@@ -318,7 +371,7 @@ def compare_maps(
     """
     comp = config["comparison"]
     rotations, scales = comp.get("rotations"), comp.get("scales")
-    scorer = scorer or default_scorer()
+    scorer = scorer or scorer_from_config(config)
     scores = scorer.score_matrix(shoemark_maps, shoeprint_maps, rotations=rotations, scales=scales)
     ranks = scorer.ranks(scores, matching_pairs)
     if progress:

@@ -89,6 +89,7 @@ class VariantBuilder:
 
     def __init__(self, lib, dev):
         self.lib, self.dev = lib, dev
+        self._tables: dict[tuple[int, int], tuple] = {}  # (in, out) -> device bounds / coefficients, kept alive here
 
     def rotate(self, maps_dev, angle: float):
         n, c, h, w = self.dev.shape(maps_dev)
@@ -115,13 +116,15 @@ class VariantBuilder:
         return self._reshape(cur, (n, c, oh, ow))
 
     def _axis(self, src, n_maps, h, w, axis, out_size):
-        bounds, coeffs, ksize = resample_tables(w if axis == 1 else h, out_size)
-        b_dev, c_dev = self.dev.to_device(bounds), self.dev.to_device(coeffs)
+        key = (w if axis == 1 else h, out_size)
+        if key not in self._tables:  # uploaded once per size pair and owned by the builder: no sync after the launch
+            bounds, coeffs, ksize = resample_tables(*key)
+            self._tables[key] = (self.dev.to_device(bounds), self.dev.to_device(coeffs), ksize)
+        b_dev, c_dev, ksize = self._tables[key]
         shape = (n_maps, h, out_size) if axis == 1 else (n_maps, out_size, w)
         out = self.dev.empty(shape, np.float32)
         self.lib.check(self.lib.spr_resample_axis(self.dev.ptr(src), self.dev.ptr(out), n_maps, h, w, axis, out_size,
                                                   self.dev.ptr(b_dev), self.dev.ptr(c_dev), ksize, self.dev.stream()))
-        self.dev.synchronize()  # the small tables must outlive the launch
         return out
 
     def _reshape(self, buf, shape):

@@ -26,6 +26,14 @@ class HostDevice:
     def stack_to_device(self, items):
         return np.ascontiguousarray(np.stack([np.asarray(i, dtype=np.float32) for i in items]))
 
+    def astype_storage(self, buf, storage: str):
+        if storage == "float32":
+            return buf
+        if storage == "float16":
+            return np.ascontiguousarray(buf.astype(np.float16))
+        bits = np.ascontiguousarray(buf, dtype=np.float32).view(np.uint32).astype(np.uint64)  # bfloat16, round to nearest even
+        return (((bits + 0x7FFF + ((bits >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
     def to_host(self, buf):
         return np.array(buf, copy=True)
 

@@ -183,6 +183,51 @@ def check_big_mode(make_scorer, monkeypatch, full):
     np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
 
 
+def check_launch_slicing(make_scorer, monkeypatch, big_c=2):
+    """HIP refuses grids of 2^32 work-items and more, so the pair launches are cut into slices of pair tiles
+    (gallery items for the direct kernel).  With the slice size forced down to ONE tile (SPR_NCC_MAX_TILES=1) a
+    multi-tile score matrix must come out bit-identical to the single launch - for the one-wave / four-wave
+    kernels, the six-wave kernel (conv3_3-sized maps: two queries per workgroup, odd query count) and the direct one."""
+    cases = [("fft", 17, 35, (2, 20, 12, 20, 12)), ("fft", 3, 17, (big_c, 128, 64, 128, 64)), ("direct", 5, 4, (2, 20, 12, 20, 12))]
+    for method, nq, ng, (c, qh, qw, gh, gw) in cases:
+        q = [synth.gallery_features(91, 100 + i, c, qh, qw) for i in range(nq)]
+        g = [synth.gallery_features(91, i, c, gh, gw) for i in range(ng)]
+        monkeypatch.delenv("SPR_NCC_MAX_TILES", raising=False)
+        whole = make_scorer(method).score_matrix(q, g)
+        monkeypatch.setenv("SPR_NCC_MAX_TILES", "1")
+        sliced = make_scorer(method).score_matrix(q, g)
+        monkeypatch.delenv("SPR_NCC_MAX_TILES")
+        np.testing.assert_array_equal(sliced, whole)
+        np.testing.assert_allclose(whole[:2, :3], oracle.similarity_matrix(q[:2], g[:3], precise=True), atol=TIGHT, rtol=0)
+
+
+def check_config_selects_the_scorer(make_from_config):
+    """[mi355x] of run.toml is what builds the scorer behind compare_maps: ncc_method picks the kernel, dtype the HBM
+    storage type of uploaded maps (scores then equal the oracle on the ROUNDED maps), max_prepared_gib the chunk budget."""
+    from shoeprint_image_retrieval_amd import _lib
+    from shoeprint_image_retrieval_amd.config import normalise
+
+    q = [synth.query_features(93, i, i, 3, 22, 14) for i in range(3)]
+    g = [synth.gallery_features(93, i, 3, 22, 14) for i in range(5)]
+    ref = oracle.similarity_matrix(q, g, precise=True)
+    for method, code in (("direct", _lib.NCC_DIRECT), ("fft", _lib.NCC_FFT)):
+        cfg = normalise({"comparison": {"n_processes": 1, "rotations": "", "scales": ""}, "mi355x": {"ncc_method": method}})
+        sc = make_from_config(cfg)
+        assert sc.plan(3, (22, 14), (22, 14)).method == code
+        np.testing.assert_array_equal(similarity.compare_maps(q, g, [0, 1, 2], cfg, scorer=sc),
+                                      oracle.compare_maps(q, g, [0, 1, 2], cfg))
+    cfg = normalise({"comparison": {"n_processes": 1, "rotations": "", "scales": ""},
+                     "mi355x": {"dtype": "float16", "max_prepared_gib": 0.001}})
+    sc = make_from_config(cfg)
+    assert sc.storage == "float16" and sc._budget() == int(0.001 * (1 << 30))
+    q16 = [a.astype(np.float16).astype(np.float32) for a in q]
+    g16 = [a.astype(np.float16).astype(np.float32) for a in g]
+    np.testing.assert_allclose(sc.score_matrix(q, g), oracle.similarity_matrix(q16, g16, precise=True), atol=TIGHT, rtol=0)
+    assert np.abs(sc.score_matrix(q, g) - ref).max() < 5e-3
+    with np.testing.assert_raises(ValueError):
+        make_from_config(normalise({"comparison": {}, "mi355x": {"ncc_method": "fastest"}}))
+
+
 def check_empty_and_degenerate_sets(scorer):
     """Edge cases as the reference behaves (run there): no queries -> empty int32 ranks; one query works;
     queries against an empty gallery -> IndexError from the rank lookup (similarity.py:386); a match index

@@ -56,6 +56,18 @@ def test_emu_big_mode(monkeypatch):
     pc.check_big_mode(lambda: emu_scorer("fft"), monkeypatch, full=False)
 
 
+def test_emu_launch_slicing(monkeypatch):
+    pc.check_launch_slicing(lambda m: emu_scorer(m), monkeypatch, big_c=1)
+
+
+def test_emu_config_selects_the_scorer():
+    from host_device import HostDevice
+    from shoeprint_image_retrieval_amd.similarity import scorer_from_config
+
+    dev = HostDevice()
+    pc.check_config_selects_the_scorer(lambda cfg: scorer_from_config(cfg, device=dev, library=emu_library()))
+
+
 def test_emu_empty_and_degenerate_sets():
     pc.check_empty_and_degenerate_sets(emu_scorer("auto"))
 

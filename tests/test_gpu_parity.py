@@ -79,6 +79,16 @@ def test_config5_multi_layer_fp16(fft_scorer):
     pc.check_config5_multi_layer_fp16(fft_scorer, channels=(256, 512, 512))
 
 
+def test_config_selects_the_scorer(lib):
+    from shoeprint_image_retrieval_amd.similarity import scorer_from_config
+
+    pc.check_config_selects_the_scorer(lambda cfg: scorer_from_config(cfg, library=lib))
+
+
+def test_launch_slicing(lib, monkeypatch):
+    pc.check_launch_slicing(lambda m: NccScorer(method=m, library=lib), monkeypatch)
+
+
 def test_big_mode(lib, monkeypatch):
     from shoeprint_image_retrieval_amd.similarity import NccScorer
 
