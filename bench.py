@@ -1,30 +1,45 @@
 #!/usr/bin/env python3
 """Headline benchmark: query x gallery NCC pairs/second on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
-Workload (config.workload, BASELINE.json configs[1]): WVU2019-shaped retrieval with VGG16 conv3_3
-features — Q = 100 queries x G = 1500 gallery items per GPU, feature stacks [256, 128, 64] float32
-(a 512x256 print through VGG16 features[:16]), seeded synthetic post-ReLU features generated on the
-device (no dataset / weights offline).  One step = one pass of the hot path from HBM-resident
-features to int32 ranks: prepare queries, prepare the gallery (chunked to the HBM budget), score all
-pairs, [N>1: all-gather the score blocks], rank the true matches.
+`--gpus N` (N > 1) invoked plainly starts its own N worker processes (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`) BEFORE this process has made any GPU call, and
+exits with their code; under torchrun (RANK / WORLD_SIZE set) the process is a worker.
 
-N > 1: the gallery is sharded (every rank owns G items: weak scaling), queries replicated, one
-RCCL all-gather of the [Q, G] float32 score blocks per step.
+Workloads (`--config`, BASELINE.json `configs`; config.workload names the one that ran):
+  2  (default, the one the metric is quoted on) WVU2019-shaped retrieval with VGG16 conv3_3 features: Q = 100 queries x
+     G = 1500 gallery items per GPU, feature stacks [256, 128, 64] float32 (a 512x256 print through VGG16 features[:16]).
+  3  ResNet50-layer3-shaped maps [1024, 32, 16] stored as bfloat16, Q = 64 x G = 10 000 per GPU (extractor bypassed).
+  4  100 k gallery over 8 GPUs: Q = 64 x G = 12 500 per GPU, conv3_3 maps stored as float16, prepared gallery in chunks.
+  5  as 4 with three feature layers per item (conv3_3, conv4_3, conv5_3, float16), score = mean of the three, fused on the
+     device; the per-layer prepare + score chains run on separate HIP streams.
+Seeded synthetic post-ReLU features generated on the device (no dataset / weights offline; queries = noisy shifted
+copies of their match with the hardest mixing weights the exact integer generator allows, signal 1 / noise 126: the
+true match then scores ~0.006 against ~0.004 for the runner-up; the parity leg compares FULL rank vectors, not only the true
+match's rank).  One step = one pass of the hot
+path from HBM-resident features to int32 ranks: prepare queries, prepare the gallery (chunked to the HBM budget), score
+all pairs, [N > 1: all-gather the score blocks], rank the true matches.
 
-The JSON line also carries `roofline` for the dominant kernel (the FFT pair kernel; duration from
-HIP events on the launch stream inside the timed region) and, at N = 1, `cpu_baseline`: the CPU
-oracle ("port" of the reference scorer) timed on the host cores on a bounded sample.
+N > 1: the gallery is sharded (every rank owns G items: weak scaling), queries replicated, one RCCL all-gather of the
+[Q, G] float32 score blocks per step.
+
+The JSON line also carries `roofline` for the dominant kernel (duration from HIP events on the launch stream inside the
+timed region) and, at N = 1, `cpu_baseline`: the CPU oracle ("port" of the reference scorer) timed on the host cores on
+a bounded sample (>= 30 s), run BEFORE this process initialises the GPU (its process pool forks), together with a parity
+check of the GPU's scores and of the full rank vectors of the sampled queries against it.
+
+`--emu` (tests only) runs the same step on the CPU emulation of the kernels with a tiny workload and the gloo backend.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -33,10 +48,21 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-C, H, W = 256, 128, 64          # VGG16 conv3_3 maps of a 512x256 print
-Q_PER_JOB, G_PER_GPU = 100, 1500
 SEED = 1234
-PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
+SIGNAL, NOISE, MAX_SHIFT = 1, 126, 3  # the hardest queries the exact integer generator makes (signal + noise < 128):
+# true-match score ~0.006 against ~0.004 for the runner-up at conv3_3 size (tools/ubench/noise_sweep.py)
+PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+LAYERS = {"conv3_3": (256, 128, 64), "conv4_3": (512, 64, 32), "conv5_3": (512, 32, 16), "resnet50_layer3": (1024, 32, 16)}
+WORKLOADS = {
+    2: dict(name="WVU2019-shaped VGG16 conv3_3 NCC", layers=["conv3_3"], storage="float32", q=100, g=1500),
+    3: dict(name="ResNet50-layer3-shaped NCC (extractor bypassed)", layers=["resnet50_layer3"], storage="bfloat16", q=64, g=10000),
+    4: dict(name="100k-gallery VGG16 conv3_3 NCC, chunked prepared gallery", layers=["conv3_3"], storage="float16", q=64, g=12500),
+    5: dict(name="multi-layer (conv3_3 + conv4_3 + conv5_3) fused NCC", layers=["conv3_3", "conv4_3", "conv5_3"],
+            storage="float16", q=64, g=12500),
+}
+EMU_LAYERS = {"conv3_3": (2, 24, 16), "conv4_3": (3, 16, 12), "conv5_3": (2, 12, 10), "resnet50_layer3": (3, 12, 10)}
 
 
 def fft_pair_flops(plan_fft, ih, iw, r_rows):
@@ -118,35 +144,154 @@ class ClockSampler:
         return out
 
 
-def cpu_baseline(sample_q, sample_g, n_proc):
-    """Time the CPU oracle's compare_maps (process pool over query chunks, scipy FFT per channel, exactly
-    the reference's formulation) on a bounded sample of the same workload."""
-    from oracle import ncc_oracle as oracle  # baseline leg only
+def usable_cores():
+    """Host cores this job may actually use: the scheduler affinity, cut down to the cgroup's CPU quota where one is set
+    (a GPU box hands a one-GPU job a share of the host: `nproc` and the affinity mask still show every core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "affinity"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(math.ceil(float(quota) / period)))
+                if q < n:
+                    n, how = q, "cgroup quota"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if "SPR_CPU_CORES" in os.environ:
+        n, how = int(os.environ["SPR_CPU_CORES"]), "SPR_CPU_CORES"
+    elif n > 16 and how == "affinity":
+        n, how = 16, "capped at the GPU box's stated 16-core share per GPU (no cgroup quota visible)"
+    return n, how
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def storage_round(a: np.ndarray, storage: str) -> np.ndarray:
+    """float32 values as they read back from their HBM storage type (the oracle then sees what the kernels see)."""
     from shoeprint_image_retrieval_amd import synth
 
-    matches = synth.default_matches(sample_q, sample_g)
-    gallery = [synth.gallery_features(SEED, g, C, H, W) for g in range(sample_g)]
-    queries = [synth.query_features(SEED, q, int(matches[q]), C, H, W) for q in range(sample_q)]
-    cfg = {"comparison": {"n_processes": n_proc, "rotations": None, "scales": None}}
+    if storage == "float16":
+        return a.astype(np.float16).astype(np.float32)
+    if storage == "bfloat16":
+        return synth.from_bfloat16_bits(synth.bfloat16_bits(a))
+    return a
+
+
+def cpu_leg(layer_shape, storage, nq_total, ng_total, target_seconds, cores, sample_q, sample_g):
+    """The CPU oracle's compare_maps (process pool over query chunks, scipy FFT per channel: the reference's
+    formulation) on a bounded sample of the SAME workload: queries 0 .. sq-1 against a gallery subset that holds their
+    true matches.  Returns pairs/s and the oracle's float32 score block + ranks for the parity check.  Runs before the
+    GPU is initialised in this process: the pool forks."""
+    from oracle import ncc_oracle as oracle  # baseline / checker leg only
+    from shoeprint_image_retrieval_amd import synth
+
+    c, h, w = layer_shape
+    matches = synth.default_matches(nq_total, ng_total)
+    sq = sample_q or max(8, min(nq_total, cores))
+    cfg = {"comparison": {"n_processes": cores, "rotations": None, "scales": None}}
+
+    def features(q_ids, g_ids):
+        gal = [storage_round(synth.gallery_features(SEED, g, c, h, w), storage) for g in g_ids]
+        qs = [storage_round(synth.query_features(SEED, q, int(matches[q]), c, h, w, max_shift=MAX_SHIFT, signal=SIGNAL,
+                                                 noise=NOISE), storage) for q in q_ids]
+        return qs, gal
+
+    sg = sample_g
+    if not sg:
+        # size the sample from a calibration pass on these very cores (four pairs per process), not from an assumed rate
+        qs, gal = features(range(min(nq_total, cores)), [0, 1, 2, 3])
+        oracle.compare_maps(qs[:1], gal[:1], [0], cfg)  # (pool start-up and imports paid once before the clock runs)
+        t0 = time.perf_counter()
+        oracle.compare_maps(qs, gal, [0] * len(qs), cfg)
+        rate = len(qs) * 4 / (time.perf_counter() - t0)
+        sg = int(min(ng_total, max(sq, math.ceil(target_seconds * rate / sq))))
+        print(f"[bench] CPU calibration: {rate:.1f} pairs/s on {cores} processes -> sample {sq} x {sg}", file=sys.stderr, flush=True)
+    g_ids = sorted({int(matches[q]) for q in range(sq)})
+    g_ids += [g for g in range(ng_total) if g not in set(g_ids)][: max(0, sg - len(g_ids))]
+    g_ids = sorted(g_ids)
+    queries, gallery = features(range(sq), g_ids)
+    local_match = [g_ids.index(int(matches[q])) for q in range(sq)]
     t0 = time.perf_counter()
-    ranks = oracle.compare_maps(queries, gallery, [int(m) for m in matches], cfg)
+    ranks, matrix = oracle.compare_maps(queries, gallery, local_match, cfg, return_matrix=True)
     dt = time.perf_counter() - t0
-    return sample_q * sample_g / dt, dt, ranks
+    return {"pairs_per_s": sq * len(g_ids) / dt, "seconds": dt, "sq": sq, "g_ids": g_ids, "local_match": local_match,
+            "ranks": np.asarray(ranks), "matrix": np.asarray(matrix, dtype=np.float32)}
 
 
-def main():
+def self_launch(argv, gpus):
+    """Plain `bench.py --gpus N`: start the N workers as fresh children (this process has not touched the GPU and never
+    will) and exit with their code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def lib_sha16(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()[:16]
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--queries", type=int, default=Q_PER_JOB)
-    ap.add_argument("--gallery-per-gpu", type=int, default=G_PER_GPU)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
+    ap.add_argument("--queries", type=int, default=0)
+    ap.add_argument("--gallery-per-gpu", type=int, default=0)
     ap.add_argument("--method", default="auto", choices=["auto", "fft", "direct"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity-sample", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true", help="(kept for old command lines: the parity check rides on the CPU leg)")
     ap.add_argument("--no-extractor", action="store_true")
-    ap.add_argument("--cpu-sample-gallery", type=int, default=0, help="gallery items in the CPU sample (0 = auto)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=45.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--cpu-sample-queries", type=int, default=0)
+    ap.add_argument("--cpu-sample-gallery", type=int, default=0)
+    ap.add_argument("--emu", action="store_true", help="tests: CPU emulation of the kernels, tiny workload, gloo")
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(argv, args.gpus)
+
+    wl = WORKLOADS[args.config]
+    layer_shapes = [(EMU_LAYERS if args.emu else LAYERS)[name] for name in wl["layers"]]
+    storage = wl["storage"]
+    nq = args.queries or (4 if args.emu else wl["q"])
+    ng_local = args.gallery_per_gpu or (6 if args.emu else wl["g"])
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    rank_env = int(os.environ.get("RANK", "0"))
+    ng_total = ng_local * world_env
+
+    # ---- CPU baseline leg first: before torch touches the GPU (fork-safe), rank 0 of a one-GPU job only ---------
+    cpu = None
+    cores, cores_how = usable_cores()
+    if world_env == 1 and rank_env == 0 and not args.no_cpu_baseline and not args.emu:
+        cpu = cpu_leg(layer_shapes[0], storage, nq, ng_total, args.cpu_seconds, cores, args.cpu_sample_queries,
+                      args.cpu_sample_gallery)
 
     import torch
 
@@ -154,126 +299,210 @@ def main():
     from shoeprint_image_retrieval_amd import parse_results, synth
     from shoeprint_image_retrieval_amd.similarity import NccScorer
 
-    rank, world, local = sdist.init_from_env()
+    rank, world, local = sdist.init_from_env("gloo" if args.emu else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    scorer = NccScorer(method=args.method)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_util import emu_scorer
+
+        scorer = emu_scorer(args.method)
+    else:
+        torch.cuda.set_device(local)
+        scorer = NccScorer(method=args.method)
     dev, lib = scorer.dev, scorer.lib
-    nq, ng_local = args.queries, args.gallery_per_gpu
-    ng_total = ng_local * world
     g0 = rank * ng_local
+
+    def as_torch(x):
+        return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+    def as_dev(x):
+        return x.numpy() if args.emu and isinstance(x, torch.Tensor) else x
 
     # ---- inputs resident in HBM before the timed region -----------------------------------------
     matches = synth.default_matches(nq, ng_total)
     match_dev = dev.to_device(matches)
-    gallery = dev.empty((ng_local, C, H, W), np.float32)
-    queries = dev.empty((nq, C, H, W), np.float32)
-    lib.check(lib.spr_synth_gallery(dev.ptr(gallery), g0, ng_local, C, H, W, SEED, dev.stream()))
-    lib.check(lib.spr_synth_queries(dev.ptr(queries), 0, nq, dev.ptr(match_dev), C, H, W, SEED, 3, 3, 2, dev.stream()))
-    plan = scorer.plan(C, (H, W), (H, W))
-    chunk = scorer.gallery_chunk_items(plan, ng_local)
-    pg = dev.empty_bytes(plan.gallery_item_bytes * chunk)
-    scores = dev.zeros((nq, ng_local), np.float32)
-    pair_events = []
 
-    def step(record):
-        pq = scorer.prepare_queries(plan, queries)
+    def synth_layer(c, h, w):
+        """(queries, gallery) of one feature layer in their storage type; generated in float32 slabs."""
+        q32 = dev.empty((nq, c, h, w), np.float32)
+        lib.check(lib.spr_synth_queries(dev.ptr(q32), 0, nq, dev.ptr(match_dev), c, h, w, SEED, MAX_SHIFT, SIGNAL, NOISE,
+                                        dev.stream()))
+        q = dev.astype_storage(q32, storage)
+        if storage == "float32":
+            g = dev.empty((ng_local, c, h, w), np.float32)
+            lib.check(lib.spr_synth_gallery(dev.ptr(g), g0, ng_local, c, h, w, SEED, dev.stream()))
+            return q, g
+        slab = 256
+        parts = []
+        tmp = dev.empty((min(slab, ng_local), c, h, w), np.float32)
+        g = None
+        for s0 in range(0, ng_local, slab):
+            n = min(slab, ng_local - s0)
+            lib.check(lib.spr_synth_gallery(dev.ptr(tmp), g0 + s0, n, c, h, w, SEED, dev.stream()))
+            part = dev.astype_storage(dev.narrow0(tmp, 0, n), storage)
+            if args.emu:
+                parts.append(np.array(part, copy=True))
+            else:
+                if g is None:
+                    g = torch.empty((ng_local, c, h, w), dtype=part.dtype, device=part.device)
+                g[s0:s0 + n].copy_(part)
+        return q, (np.concatenate(parts) if args.emu else g)
+
+    layers = [synth_layer(*shape) for shape in layer_shapes]
+    plans = [scorer.plan(c, (h, w), (h, w), dtype=storage) for (c, h, w) in layer_shapes]
+    budget = scorer._budget() // max(1, len(layers))
+    chunks = [int(max(1, min(ng_local, budget // max(1, p.gallery_item_bytes), 65535))) for p in plans]
+    pgs = [dev.empty_bytes(p.gallery_item_bytes * ch) for p, ch in zip(plans, chunks)]
+    layer_scores = [dev.zeros((nq, ng_local), np.float32) for _ in layers]
+    scores = layer_scores[0] if len(layers) == 1 else dev.zeros((nq, ng_local), np.float32)
+    pair_events = []
+    # config 5: one HIP stream per feature layer (prepare + score chains overlap), joined by events before the fusion
+    streams = [torch.cuda.Stream() for _ in layers] if (len(layers) > 1 and not args.emu) else None
+
+    def score_layer(k, record):
+        (q, g), plan, chunk, pg, out = layers[k], plans[k], chunks[k], pgs[k], layer_scores[k]
+        pq = scorer.prepare_queries(plan, q)
         for start in range(0, ng_local, chunk):
             n = min(chunk, ng_local - start)
-            scorer.prepare_gallery(plan, dev.narrow0(gallery, start, n), out=pg)
-            if record:
+            scorer.prepare_gallery(plan, dev.narrow0(g, start, n), out=pg)
+            if record and k == 0:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            scorer.score_prepared(plan, pq, nq, pg, n, scores, ng_local, start)
-            if record:
+            scorer.score_prepared(plan, pq, nq, pg, n, out, ng_local, start)
+            if record and k == 0:
                 e1.record()
                 pair_events.append((e0, e1, nq * n))
-        full = sdist.gather_score_blocks(scores, ng_total)
+
+    def step(record):
+        if streams:
+            main_stream = torch.cuda.current_stream()
+            for k, s in enumerate(streams):
+                s.wait_stream(main_stream)
+                with torch.cuda.stream(s):
+                    score_layer(k, record)
+            for s in streams:
+                main_stream.wait_stream(s)
+        else:
+            for k in range(len(layers)):
+                score_layer(k, record and not args.emu)
+        if len(layers) > 1:
+            w = 1.0 / len(layers)
+            for k, ls in enumerate(layer_scores):
+                lib.check(lib.spr_scores_fuse(dev.ptr(scores), dev.ptr(ls), nq * ng_local, 0.0 if k == 0 else 1.0, w,
+                                              dev.stream()))
+        full = as_dev(sdist.gather_score_blocks(as_torch(scores), ng_total))
         return scorer.ranks_device(full, match_dev), full
+
+    def sync():
+        if not args.emu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(False)
     sampler = None
-    if rank == 0:
+    if rank == 0 and not args.emu:
         try:
             pr = torch.cuda.get_device_properties(local)
             sampler = ClockSampler(f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
         except (AttributeError, OSError, ValueError):
             sampler = None
     sdist.barrier()
-    torch.cuda.synchronize()
+    sync()
     if sampler:
         sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ranks_dev, full = step(True)
-    torch.cuda.synchronize()
+    sync()
     sdist.barrier()
-    dt = sdist.max_over_ranks(time.perf_counter() - t0, device=gallery.device)
+    dt = sdist.max_over_ranks(time.perf_counter() - t0, device=None if args.emu else layers[0][1].device)
     observed = sampler.stop() if sampler else None
 
     pairs_per_step = nq * ng_total
     value = pairs_per_step * args.steps / dt
     ranks = dev.to_host(ranks_dev)
 
-    # ---- roofline of the dominant kernel (pair kernel), from the events recorded above ----------
-    pair_ms = sum(a.elapsed_time(b) for a, b, _ in pair_events)
-    pair_pairs = sum(p for _, _, p in pair_events)
-    launches = len(pair_events)
-    ih, iw = H - 4, W - 4
-    method = plan.method
-    if method == 1:
-        r_rows = 16 * math.ceil(ih / 16) if plan.fft_size[0] == 256 else ih
-        flops_pair = fft_pair_flops(plan.fft_size, ih, iw, r_rows) * C
-        kernel = "pair_fft_kernel"
-    else:
-        flops_pair = direct_pair_flops(ih, iw, ih, iw) * C
-        kernel = "pair_direct_kernel"
-    achieved = (flops_pair * pair_pairs) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
-    roofline = {
-        "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-        "kernel": kernel, "launches": launches, "avg_launch_ms": round(pair_ms / max(1, launches), 3),
-        "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 4),
-        "direct_form_gflop_per_pair": round(direct_pair_flops(ih, iw, ih, iw) * C / 1e9, 3),
-        "kernel_time_share": round(pair_ms * 1e-3 / dt, 3),
-        "note": "fp32 FFT butterflies run on the vector ALU; FP32 vector peak = FP32 MFMA peak = 157.3 TFLOP/s",
-    }
+    # ---- roofline of the dominant kernel (the first layer's pair kernel), from the events recorded above ----------
+    c0, h0, w0 = layer_shapes[0]
+    plan0 = plans[0]
+    ih, iw = h0 - 4, w0 - 4
+    roofline = None
+    if pair_events:
+        pair_ms = sum(a.elapsed_time(b) for a, b, _ in pair_events)
+        pair_pairs = sum(p for _, _, p in pair_events)
+        launches = len(pair_events)
+        if args.config == 3:
+            # small maps: the kernel streams prepared spectra from L2 / HBM; SURVEY §8d prices it against HBM with the
+            # compulsory bytes of an unbatched pair = one gallery feature tensor (bf16: 1.05 MB)
+            bytes_pair = c0 * h0 * w0 * 2
+            ach = bytes_pair * pair_pairs / (pair_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "kernel": "pair_fft_kernel (one wave per pair)",
+                        "launches": launches, "avg_launch_ms": round(pair_ms / launches, 3),
+                        "algorithmic_bytes_per_pair": bytes_pair,
+                        "note": "SURVEY 8d: one bf16 gallery tensor per pair (queries not batched)"}
+        else:
+            if plan0.method == 1:
+                r_rows = 16 * math.ceil(ih / 16) if plan0.fft_size[0] == 256 else ih
+                flops_pair = fft_pair_flops(plan0.fft_size, ih, iw, r_rows) * c0
+                kernel = "pair6_kernel" if tuple(plan0.fft_size) == (192, 96) and os.environ.get("SPR_NCC_SIX", "1") != "0" \
+                    else "pair_fft_kernel"
+            else:
+                flops_pair = direct_pair_flops(ih, iw, ih, iw) * c0
+                kernel = "pair_direct_kernel"
+            achieved = (flops_pair * pair_pairs) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
+            roofline = {
+                "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "kernel": kernel, "launches": launches, "avg_launch_ms": round(pair_ms / max(1, launches), 3),
+                "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 4),
+                "direct_form_gflop_per_pair": round(direct_pair_flops(ih, iw, ih, iw) * c0 / 1e9, 3),
+                "kernel_time_share": round(pair_ms * 1e-3 / dt, 3),
+                "note": "fp32 FFT butterflies on the vector ALU (no MFMA instructions); peak = FP32 vector peak 157.3 TFLOP/s; "
+                        "achieved = nominal 5 N log2 N flops of the FFT form / kernel time",
+            }
+            if observed:
+                # what the chip actually ran at during the timed steps (power-limited: see DESIGN.md §5)
+                roofline["observed"] = dict(observed, nominal_sclk_mhz=2400, frac_at_observed_clock=round(
+                    achieved / (PEAK_FP32_TFLOPS * observed["sclk_mhz_median"] / 2400.0), 4))
+            # HBM-side traffic per launch: not measurable from inside the run (PMC passes need rocprofv3); the committed
+            # figure of the counter passes of THIS command is used only while it is keyed to the very library build that is
+            # running (sha256 of the .so), otherwise null
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r02_rocprof_summary.json")))
+                key = prof.get("pair kernel traffic per launch", {})
+                if (args.config, nq, ng_local, world) == (2, wl["q"], wl["g"], 1) and key.get("lib_sha16") == lib_sha16(lib.path):
+                    roofline["traffic"] = key["hbm_bytes_per_launch"]
+                    roofline["traffic_unit"] = "bytes per launch (memory-side L2 requests incl. Infinity-Cache hits)"
+            except (OSError, KeyError, ValueError):
+                pass
 
-    if observed:
-        # what the chip actually ran at during the timed steps (power-limited: see DESIGN.md §5); `frac` above stays
-        # against the nominal peak, this is the same achieved rate against the peak at the observed clock
-        roofline["observed"] = dict(observed, nominal_sclk_mhz=2400,
-                                    frac_at_observed_clock=round(achieved / (PEAK_FP32_TFLOPS * observed["sclk_mhz_median"] / 2400.0), 4))
-    # HBM-side traffic of the pair kernel per launch: from the committed rocprofv3 --pmc passes of THIS
-    # command (profiles/, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), default workload only.
-    try:
-        if (nq, ng_local, world, method) == (Q_PER_JOB, G_PER_GPU, 1, 1):
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")))
-            roofline["traffic"] = prof["pair_fft_kernel traffic per launch"]["hbm_bytes_per_launch"]
-            roofline["traffic_unit"] = "bytes per launch (memory-side L2 requests incl. Infinity-Cache hits)"
-    except (OSError, KeyError, ValueError):
-        pass
-
+    shapes = " + ".join(f"[{c},{h},{w}]" for c, h, w in layer_shapes)
     out = {
         "metric": "query x gallery NCC pairs/sec", "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"WVU2019-shaped VGG16 conv3_3 NCC: Q={nq} x G={ng_total} "
-                               f"({ng_local}/GPU), features [{C},{H},{W}] f32, rotations/scales none",
-                   "method": {1: "fft", 2: "direct"}[method], "fft_grid": list(plan.fft_size),
-                   "gallery_chunk": chunk, "parallelism": f"gallery-shard x{world}"},
+        "config": {"workload": f"config {args.config}: {wl['name']}: Q={nq} x G={ng_total} ({ng_local}/GPU), features {shapes} "
+                               f"stored as {storage}, rotations/scales none, queries signal {SIGNAL} / noise {NOISE}",
+                   "method": {1: "fft", 2: "direct"}[plan0.method], "fft_grid": list(plan0.fft_size),
+                   "gallery_chunk": chunks[0], "gallery_chunks_per_step": math.ceil(ng_local / chunks[0]),
+                   "storage": storage, "parallelism": f"gallery-shard x{world}",
+                   "streams": len(streams) if streams else 1},
         "rank1": round(parse_results.rank1(ranks), 4), "mAP": round(parse_results.mean_average_precision(ranks), 4),
-        "roofline": roofline,
+        "mean_rank": round(float(np.mean(ranks)), 2),
     }
+    if roofline:
+        out["roofline"] = roofline
+    if args.emu:
+        out["data"] = "synthetic (CPU emulation of the kernels: test mode, not a measurement)"
 
-    if rank == 0 and not args.no_extractor:
+    if rank == 0 and not args.no_extractor and not args.emu and args.config == 2:
         # extractor reported separately (SURVEY §8d): VGG16 features[:16] on 512x256 prints, images/s
         from shoeprint_image_retrieval_amd import network
         model = network.Model({"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 16)
-        imgs = torch.randint(0, 256, (32, 2 * H * 2, 2 * W * 2), dtype=torch.uint8, device=gallery.device)
+        imgs = torch.randint(0, 256, (32, 512, 256), dtype=torch.uint8, device=layers[0][1].device)
         model.extract_device(imgs)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -290,38 +519,40 @@ def main():
                             "weights": "seeded synthetic"}
         del model, imgs
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # the GPU box gives a one-GPU job a 16-core share of the host (nproc still reports every core)
-        cores = int(os.environ.get("SPR_CPU_CORES", min(os.cpu_count() or 1, 16)))
-        sq = min(nq, cores)
-        sg = args.cpu_sample_gallery or max(2, min(ng_local, int(round(20.0 * 1.9 * cores / max(1, sq)))))
-        v, secs, cpu_ranks = cpu_baseline(sq, sg, cores)
+    if cpu is not None:
+        v = cpu["pairs_per_s"]
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-                               "sample": f"Q={sq} x G={sg} of the same workload, oracle compare_maps with a "
-                                         f"{cores}-process pool, {secs:.1f} s",
-                               "gpu_over_cpu": round(value / v, 1)}
-        if not args.no_parity_sample:
-            # same leg, same checker: the oracle on pairs of the ACTUAL workload (features regenerated by the numpy
-            # twin of the device generator) against the scores the timed steps produced
+                               "cores_from": cores_how, "cpu_model": cpu_model(),
+                               "sample": f"queries 0..{cpu['sq'] - 1} x {len(cpu['g_ids'])} gallery items (their matches included) of the "
+                                         f"same workload, first layer, oracle compare_maps with a {cores}-process pool, "
+                                         f"{cpu['seconds']:.1f} s",
+                               "per_core": round(v / cores, 2), "gpu_over_cpu": round(value / v, 1)}
+        if len(layers) == 1:
+            # parity on the ACTUAL workload: the GPU's scores of the sampled block against the oracle's, and the full
+            # rank vector of every sampled query (ranked within the sampled gallery, by the oracle's rule, from GPU scores)
+            full_h = dev.to_host(full)
+            block = full_h[np.ix_(range(cpu["sq"]), cpu["g_ids"])]
+            err = float(np.abs(block - cpu["matrix"]).max())
             from oracle import ncc_oracle as oracle
 
-            full_h = dev.to_host(full)
-            errs = []
-            for qi in (0, nq - 1):
-                qf = synth.query_features(SEED, qi, int(matches[qi]), C, H, W)
-                for gi in (int(matches[qi]), (int(matches[qi]) + 1) % ng_total):
-                    ref = max(0.0, float(oracle.get_similarity(qf, synth.gallery_features(SEED, gi, C, H, W), precise=True)))
-                    errs.append(abs(ref - float(full_h[qi, gi])))
-            out["parity_sample"] = {"pairs": len(errs), "max_abs_err_vs_oracle": float(f"{max(errs):.3e}"), "tolerance": 1e-4}
+            gpu_ranks = np.array([oracle.rank_true_match(block[i], cpu["local_match"][i]) for i in range(cpu["sq"])])
+            order_equal = all(np.array_equal(np.argsort(-block[i], kind="stable"), np.argsort(-cpu["matrix"][i], kind="stable"))
+                              for i in range(cpu["sq"]))
+            out["parity_sample"] = {"pairs": int(block.size), "queries": int(cpu["sq"]),
+                                    "max_abs_err_vs_oracle": float(f"{err:.3e}"), "tolerance": 1e-4,
+                                    "true_match_ranks_equal": bool(np.array_equal(gpu_ranks, cpu["ranks"])),
+                                    "full_rank_vectors_equal": bool(order_equal),
+                                    "oracle_ranks": [int(r) for r in cpu["ranks"]]}
     if rank == 0:
         print(json.dumps(out))
     sys.stdout.flush()
-    if world > 1:  # leave the group together (rank 0 ran the extra legs above) and tear RCCL down cleanly
+    if world > 1:  # leave the group together (rank 0 ran the extra legs above) and tear the backend down cleanly
         import torch.distributed as dist
 
         sdist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

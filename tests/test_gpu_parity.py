@@ -86,6 +86,8 @@ def test_config_selects_the_scorer(lib):
 
 
 def test_launch_slicing(lib, monkeypatch):
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+
     pc.check_launch_slicing(lambda m: NccScorer(method=m, library=lib), monkeypatch)
 
 
