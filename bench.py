@@ -498,6 +498,26 @@ def main(argv=None):
     if args.emu:
         out["data"] = "synthetic (CPU emulation of the kernels: test mode, not a measurement)"
 
+    if rank == 0 and not args.no_extractor and not args.emu and args.config == 3:
+        # the build-defined ResNet50-layer3 extractor, reported separately (17.13 GFLOP per 512x256 image)
+        from shoeprint_image_retrieval_amd import network
+        model = network.Model({"model": {"type": "ResNet50", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 7)
+        imgs = torch.randint(0, 256, (32, 512, 256), dtype=torch.uint8, device=layers[0][1].device)
+        model.extract_device(imgs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            model.extract_device(imgs)
+        e1.record()
+        torch.cuda.synchronize()
+        ems = e0.elapsed_time(e1) / 3
+        out["extractor"] = {"metric": "ResNet50 layer3 images/s (512x256 uint8 -> [1024,32,16] f32)",
+                            "value": round(32 / ems * 1e3, 1), "batch": 32, "ms_per_batch": round(ems, 2),
+                            "achieved_tflops": round(17.13 * 32 / ems, 2), "peak_tflops": PEAK_FP32_TFLOPS,
+                            "frac": round(17.13 * 32 / ems / PEAK_FP32_TFLOPS, 4), "bound": "mfma", "dtype": "f32",
+                            "weights": "seeded synthetic"}
+        del model, imgs
     if rank == 0 and not args.no_extractor and not args.emu and args.config == 2:
         # extractor reported separately: VGG16 features[:16] on 512x256 prints, images/s
         from shoeprint_image_retrieval_amd import network

@@ -219,6 +219,31 @@ int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, in
                       int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
                       void* workspace, float* out, spr_stream_t stream);
 
+/* ------------------------------------------------------------------ ResNet50 extractor (build-defined)
+ * BASELINE.json config 3 asks for "ResNet50 layer3 summed maps"; the reference has no ResNet branch (network.py:121-182)
+ * and its truncation rule `list(model.features.children())[:block]` (network.py:185) has no `.features` to act on there.
+ * Defined here as torchvision's resnet50 (v1.5: stride on the 3x3 convolution) cut after `block` of its top-level children
+ * [conv1, bn1, relu, maxpool, layer1, layer2, layer3]: block = 5 / 6 / 7 -> [256|512|1024, H/4|H/8|H/16, W/4|W/8|W/16].
+ * Same calling sequence as the VGG plan: conv shapes in module order (conv1; per bottleneck conv1, conv2, conv3 and, in a
+ * layer's first block, the downsample convolution), weights [cout][cin][k][k] + bias with eval-mode BatchNorm folded in
+ * by the caller, packed once; forward = pre-processing (network.py:60-71) + stem + max pool + bottlenecks on the fp32
+ * matrix cores, float32 NCHW out.  role: 0 stem, 1/2/3 a bottleneck's convolutions, 4 downsample. */
+typedef struct spr_resnet_plan spr_resnet_plan;
+int spr_resnet_plan_create(int32_t block, spr_resnet_plan** plan_out);
+void spr_resnet_plan_destroy(spr_resnet_plan* plan);
+int spr_resnet_num_convs(const spr_resnet_plan* plan);
+int spr_resnet_conv_shape(const spr_resnet_plan* plan, int32_t i, int32_t* cin, int32_t* cout, int32_t* ksize,
+                          int32_t* stride, int32_t* role);
+int spr_resnet_output_shape(const spr_resnet_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels, int32_t* out_h,
+                            int32_t* out_w);
+size_t spr_resnet_packed_bytes(const spr_resnet_plan* plan);
+int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const* weights, const float* const* biases, void* packed,
+                            spr_stream_t stream);
+size_t spr_resnet_workspace_bytes(const spr_resnet_plan* plan, int64_t n, int32_t in_h, int32_t in_w);
+int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                       int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed, void* workspace,
+                       float* out, spr_stream_t stream);
+
 /* ------------------------------------------------------------------ synthetic data
  * Bench/test support: the device twin of shoeprint_image_retrieval_amd/synth.py (bit-identical
  * float32 values).  out: device float32 [n, C, h, w]. */

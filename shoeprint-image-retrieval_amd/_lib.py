@@ -72,6 +72,16 @@ SIGNATURES = {
     "spr_vgg16_workspace_bytes": (_SZ, [_VP, _I64, _I32, _I32]),
     "spr_vgg16_forward": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     _VP, _VP, _VP, _VP]),
+    "spr_resnet_plan_create": (C.c_int, [_I32, C.POINTER(_VP)]),
+    "spr_resnet_plan_destroy": (None, [_VP]),
+    "spr_resnet_num_convs": (C.c_int, [_VP]),
+    "spr_resnet_conv_shape": (C.c_int, [_VP, _I32] + [C.POINTER(_I32)] * 5),
+    "spr_resnet_output_shape": (C.c_int, [_VP, _I32, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "spr_resnet_packed_bytes": (_SZ, [_VP]),
+    "spr_resnet_pack_weights": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), _VP, _VP]),
+    "spr_resnet_workspace_bytes": (_SZ, [_VP, _I64, _I32, _I32]),
+    "spr_resnet_forward": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     _VP, _VP, _VP, _VP]),
     "spr_synth_gallery": (C.c_int, [_VP, _I64, _I64, _I32, _I32, _I32, C.c_uint64, _VP]),
     "spr_synth_queries": (C.c_int, [_VP, _I64, _I64, _VP, _I32, _I32, _I32, C.c_uint64, _I32, _I32, _I32, _VP]),
 }

@@ -1,0 +1,420 @@
+// ResNet50 feature extractor through layer1 / layer2 / layer3 (BASELINE.json config 3: "ResNet50 layer3 summed maps").
+//
+// The reference has no ResNet (network.py:121-182 lists VGG, EfficientNet and DenseNet) and its truncation
+// `list(model.features.children())[:block]` (network.py:185) would not apply to torchvision's resnet50, which has no
+// `.features`; this extractor is therefore BUILD-DEFINED: torchvision's resnet50 v1.5 graph (stride on the 3x3 convolution
+// of a bottleneck), truncated after `block` of its top-level children [conv1, bn1, relu, maxpool, layer1, layer2, layer3],
+// block = 5 / 6 / 7.  Eval-mode BatchNorm is an affine map per channel and is folded into the preceding convolution by
+// the host, so the kernels see convolution + bias only.
+//
+// Kernels (activations NHWC float32 between layers, NCHW out of the last one, as the NCC prep kernels read them):
+//   stem_kernel      7x7 / stride 2 / pad 3, 3 -> 64, with ToTensor / repeat(3) / Normalize fused in front (zero padding
+//                    of the NORMALISED tensor) and ReLU behind; plain FMA (K = 147, 3.6 % of the flops).
+//   maxpool3_kernel  3x3 / stride 2 / pad 1.
+//   conv_gemm_kernel every other convolution (1x1 and 3x3, stride 1 or 2) as an implicit GEMM on the fp32 matrix cores
+//                    (v_mfma_f32_16x16x4_f32, exact f32): M = images x output pixels, N = output channels, K = taps x
+//                    input channels.  Workgroup = 64 pixels x 64 channels, 4 waves x (16 pixels x 64 channels); per K
+//                    chunk of 16 the A tile (gathered rows of 16 contiguous channels, zero fill = padding) and the B
+//                    tile (packed filter slab) are staged in LDS from registers loaded one chunk ahead.  Epilogue: bias,
+//                    residual add, ReLU.
+// Arithmetic: 17.13 GFLOP per 512x256 image through layer3; bound: fp32 MFMA 157 TFLOP/s.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+constexpr int kGM = 64, kGN = 64, kGK = 16;  // GEMM tile of a workgroup: pixels x channels x K chunk
+constexpr int kGS = 20;                        // LDS row stride (floats) of a 16-float row: 16-byte aligned, 5 quads
+                                               // -> the 16 lanes of an MFMA operand read hit different banks
+
+struct RConv {
+  int cin, cout, ks, stride;
+  int relu;      // ReLU in the epilogue
+  int res;       // 0: none, 1: add the block input, 2: add the downsample branch's output
+  int role;      // 0 stem, 1 conv1, 2 conv2, 3 conv3, 4 downsample
+  size_t w_off, b_off;
+};
+
+// ---------------------------------------------------------------- parameter packing
+// stem: [tap*3 + c][64]   |   GEMM convs: [cout/64][K/16][n:64][k:16], K index = tap * cin + c
+__global__ void __launch_bounds__(kThreads)
+rpack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ packed, size_t w_off,
+             size_t b_off, int cin, int cout, int ks, int stem) {
+  const int taps = ks * ks;
+  const size_t total = static_cast<size_t>(cout) * cin * taps;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int tap = static_cast<int>(i % taps);  // torch layout [n][c][ky][kx]
+    const int c = static_cast<int>((i / taps) % cin);
+    const int n = static_cast<int>(i / (static_cast<size_t>(taps) * cin));
+    size_t dst;
+    if (stem) {
+      dst = static_cast<size_t>(tap * 3 + c) * cout + n;
+    } else {
+      const int k = tap * cin + c;
+      const int chunks = taps * cin / kGK;
+      dst = ((static_cast<size_t>(n / kGN) * chunks + k / kGK) * kGN + n % kGN) * kGK + k % kGK;
+    }
+    packed[w_off + dst] = w[i];
+  }
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
+}
+
+// ---------------------------------------------------------------- stem: 7x7 s2 p3, 3 -> 64, pre-processing + ReLU fused
+// grid = (tiles of 8x8 output pixels, images); out NHWC [n][Ho][Wo][64]
+__global__ void __launch_bounds__(kThreads)
+stem_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2, float s0,
+            float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias, float* __restrict__ out) {
+  constexpr int kT = 8, kP = 2 * kT + 5;  // 21 x 21 input patch
+  __shared__ float patch[kP * kP * 3];
+  __shared__ float wl[147 * 64];
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int tiles_x = ceil_div(Wo, kT);
+  const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
+  const int oy0 = ty * kT, ox0 = tx * kT;
+  const size_t img = blockIdx.y;
+  const int tid = static_cast<int>(threadIdx.x);
+  const float mean[3] = {m0, m1, m2}, istd[3] = {s0, s1, s2};
+  for (int i = tid; i < 147 * 64; i += kThreads) wl[i] = wts[i];
+  for (int i = tid; i < kP * kP; i += kThreads) {
+    const int py = i / kP, px = i % kP;
+    const int y = 2 * oy0 - 3 + py, x = 2 * ox0 - 3 + px;
+    const bool in = y >= 0 && y < H && x >= 0 && x < W;
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.0f;  // zero padding of the NORMALISED tensor
+      if (in) {
+        const size_t pix = (img * H + y) * static_cast<size_t>(W) + x;
+        const float u = static_cast<float>(in_channels == 1 ? images[pix] : images[pix * 3 + c]);
+        v = (u / 255.0f - mean[c]) * istd[c];
+      }
+      patch[i * 3 + c] = v;
+    }
+  }
+  __syncthreads();
+  const int n = tid & 63, part = tid >> 6;  // lane = output channel; wave `part` takes output rows 2 part, 2 part + 1
+  const float b = bias[n];
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = b;
+  for (int dy = 0; dy < 7; ++dy)
+    for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float wv = wl[((dy * 7 + dx) * 3 + c) * 64 + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int py = 2 * (2 * part + i / 8) + dy, px = 2 * (i % 8) + dx;
+          acc[i] = fmaf(patch[(py * kP + px) * 3 + c], wv, acc[i]);
+        }
+      }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int oy = oy0 + 2 * part + i / 8, ox = ox0 + i % 8;
+    if (oy < Ho && ox < Wo) out[((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + n] = fmaxf(acc[i], 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------- 3x3 / stride 2 / pad 1 max pool, NHWC
+__global__ void __launch_bounds__(kThreads)
+maxpool3_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, size_t total) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C);
+    size_t p = i / C;
+    const int ox = static_cast<int>(p % Wo); p /= Wo;
+    const int oy = static_cast<int>(p % Ho);
+    const size_t img = p / Ho;
+    float m = -3.402823466e38f;  // (padding never wins: every window holds at least one real pixel)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y = 2 * oy + dy, x = 2 * ox + dx;
+        if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, in[((img * H + y) * static_cast<size_t>(W) + x) * C + c]);
+      }
+    out[i] = m;
+  }
+}
+
+// ---------------------------------------------------------------- implicit-GEMM convolution on fp32 MFMA
+// grid = (ceil(M / 64), cout / 64).  in NHWC [n][H][W][cin]; out NHWC [n][Ho][Wo][cout] (or NCHW); res NHWC like out.
+template <int KS, int STRIDE>
+__global__ void __launch_bounds__(kThreads, 2)
+conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin, int cout, const float* __restrict__ wts,
+                 const float* __restrict__ bias, const float* __restrict__ res, int relu, int nchw,
+                 float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float A[kGM * kGS];
+  __shared__ __attribute__((aligned(16))) float B[kGN * kGS];
+  constexpr int PAD = KS / 2;
+  const int Ho = (H + 2 * PAD - KS) / STRIDE + 1, Wo = (W + 2 * PAD - KS) / STRIDE + 1;
+  const long long M = static_cast<long long>(n_img) * Ho * Wo;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int p = lane & 15, q = lane >> 4;  // MFMA lane coordinates: row/col index, k index
+  const int cb = static_cast<int>(blockIdx.y);
+  const long long m0 = static_cast<long long>(blockIdx.x) * kGM;
+  const int cchunks = cin / kGK, chunks = KS * KS * cchunks;
+
+  // this thread stages quarter `sq` (4 floats) of row `sr` of both tiles
+  const int sr = tid >> 2, sq = tid & 3;
+  const long long pm = m0 + sr;  // pixel of the A row
+  const bool pm_ok = pm < M;
+  int py = 0, px = 0;
+  size_t pimg = 0;
+  if (pm_ok) {
+    px = static_cast<int>(pm % Wo);
+    py = static_cast<int>((pm / Wo) % Ho);
+    pimg = static_cast<size_t>(pm / (static_cast<long long>(Wo) * Ho));
+  }
+  const float* wbase = wts + static_cast<size_t>(cb) * chunks * (kGN * kGK) + sr * kGK + sq * 4;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra, rb;
+  auto request = [&](int ch) {
+    const int tap = ch / cchunks, cc = ch - tap * cchunks;
+    const int dy = tap / KS, dx = tap - dy * KS;
+    const int y = py * STRIDE + dy - PAD, x = px * STRIDE + dx - PAD;
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pm_ok && y >= 0 && y < H && x >= 0 && x < W)
+      ra = *reinterpret_cast<const float4*>(in + ((pimg * H + y) * static_cast<size_t>(W) + x) * cin + cc * kGK + sq * 4);
+    rb = *reinterpret_cast<const float4*>(wbase + static_cast<size_t>(ch) * (kGN * kGK));
+  };
+  request(0);
+  for (int ch = 0; ch < chunks; ++ch) {
+    __syncthreads();  // the previous chunk's fragments are consumed
+    *reinterpret_cast<float4*>(A + sr * kGS + sq * 4) = ra;
+    *reinterpret_cast<float4*>(B + sr * kGS + sq * 4) = rb;
+    __syncthreads();
+    if (ch + 1 < chunks) request(ch + 1);
+    // the k index of MFMA step j is {4 q + j}: any partition of the 16 works as long as A and B agree
+    const float4 a = *reinterpret_cast<const float4*>(A + (wave * 16 + p) * kGS + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 b = *reinterpret_cast<const float4*>(B + (j * 16 + p) * kGS + q * 4);
+      acc[j] = mfma_f32_16x16x4(a.x, b.x, acc[j]);
+      acc[j] = mfma_f32_16x16x4(a.y, b.y, acc[j]);
+      acc[j] = mfma_f32_16x16x4(a.z, b.z, acc[j]);
+      acc[j] = mfma_f32_16x16x4(a.w, b.w, acc[j]);
+    }
+  }
+  // ---- epilogue: lane (q, p) owns pixels m0 + 16 wave + 4 q + r (r = 0..3), channel cb*64 + 16 j + p
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long m = m0 + wave * 16 + 4 * q + r;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = cb * kGN + j * 16 + p;
+      float v = acc[j][r] + bias[ch];
+      if (res) v += res[static_cast<size_t>(m) * cout + ch];
+      if (relu) v = fmaxf(v, 0.0f);
+      if (nchw) {
+        const int ox = static_cast<int>(m % Wo), oy = static_cast<int>((m / Wo) % Ho);
+        const size_t img = static_cast<size_t>(m / (static_cast<long long>(Wo) * Ho));
+        out[((img * cout + ch) * Ho + oy) * static_cast<size_t>(Wo) + ox] = v;
+      } else {
+        out[static_cast<size_t>(m) * cout + ch] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace spr
+
+struct spr_resnet_plan {
+  int block;                       // top-level children kept: 5 = layer1, 6 = layer2, 7 = layer3
+  std::vector<spr::RConv> convs;   // in torchvision's module order (conv1; per bottleneck conv1, conv2, conv3, [downsample])
+  size_t packed_floats;
+};
+
+using namespace spr;
+
+extern "C" int spr_resnet_plan_create(int32_t block, spr_resnet_plan** plan_out) {
+  if (!plan_out) { set_error("spr_resnet_plan_create: null pointer"); return SPR_ERR_ARG; }
+  *plan_out = nullptr;
+  if (block < 5 || block > 7) {
+    set_error("spr_resnet_plan_create: block %d: the truncation must end after layer1 (5), layer2 (6) or layer3 (7)", block);
+    return SPR_ERR_ARG;
+  }
+  spr_resnet_plan* plan = new (std::nothrow) spr_resnet_plan();
+  if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
+  plan->block = block;
+  size_t off = 0;
+  auto add = [&](int cin, int cout, int ks, int stride, int relu, int res, int role) {
+    RConv c{};
+    c.cin = cin; c.cout = cout; c.ks = ks; c.stride = stride; c.relu = relu; c.res = res; c.role = role;
+    c.w_off = off; off += static_cast<size_t>(cout) * cin * ks * ks;
+    c.b_off = off; off += static_cast<size_t>(cout);
+    off = (off + 3) / 4 * 4;
+    plan->convs.push_back(c);
+  };
+  add(3, 64, 7, 2, 1, 0, 0);
+  static const int blocks_per_layer[3] = {3, 4, 6};
+  int cin = 64;
+  for (int layer = 0; layer < block - 4; ++layer) {
+    const int mid = 64 << layer;
+    for (int b = 0; b < blocks_per_layer[layer]; ++b) {
+      const int stride = (b == 0 && layer > 0) ? 2 : 1;
+      add(cin, mid, 1, 1, 1, 0, 1);
+      add(mid, mid, 3, stride, 1, 0, 2);
+      add(mid, 4 * mid, 1, 1, 1, b == 0 ? 2 : 1, 3);
+      if (b == 0) add(cin, 4 * mid, 1, stride, 0, 0, 4);
+      cin = 4 * mid;
+    }
+  }
+  plan->packed_floats = off;
+  *plan_out = plan;
+  return SPR_OK;
+}
+
+extern "C" void spr_resnet_plan_destroy(spr_resnet_plan* plan) { delete plan; }
+
+extern "C" int spr_resnet_num_convs(const spr_resnet_plan* plan) {
+  return plan ? static_cast<int>(plan->convs.size()) : SPR_ERR_ARG;
+}
+
+extern "C" int spr_resnet_conv_shape(const spr_resnet_plan* plan, int32_t i, int32_t* cin, int32_t* cout, int32_t* ksize,
+                                     int32_t* stride, int32_t* role) {
+  if (!plan || !cin || !cout || !ksize || !stride || !role || i < 0 || i >= static_cast<int>(plan->convs.size())) {
+    set_error("spr_resnet_conv_shape: bad argument");
+    return SPR_ERR_ARG;
+  }
+  const RConv& c = plan->convs[i];
+  *cin = c.cin; *cout = c.cout; *ksize = c.ks; *stride = c.stride; *role = c.role;
+  return SPR_OK;
+}
+
+static void resnet_dims(const spr_resnet_plan* plan, int in_h, int in_w, int* c, int* h, int* w) {
+  int hh = (in_h + 1) / 2, ww = (in_w + 1) / 2;  // conv1: 7x7 s2 p3
+  hh = (hh + 1) / 2; ww = (ww + 1) / 2;          // maxpool 3x3 s2 p1
+  for (int layer = 1; layer < plan->block - 4; ++layer) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; }  // 3x3 s2 p1
+  *c = 256 << (plan->block - 5); *h = hh; *w = ww;
+}
+
+extern "C" int spr_resnet_output_shape(const spr_resnet_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels,
+                                       int32_t* out_h, int32_t* out_w) {
+  if (!plan || !channels || !out_h || !out_w || in_h < 1 || in_w < 1) {
+    set_error("spr_resnet_output_shape: bad argument");
+    return SPR_ERR_ARG;
+  }
+  int c, h, w;
+  resnet_dims(plan, in_h, in_w, &c, &h, &w);
+  *channels = c; *out_h = h; *out_w = w;
+  return SPR_OK;
+}
+
+extern "C" size_t spr_resnet_packed_bytes(const spr_resnet_plan* plan) {
+  return plan ? plan->packed_floats * sizeof(float) : 0;
+}
+
+extern "C" int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const* weights, const float* const* biases,
+                                       void* packed, spr_stream_t stream) {
+  if (!plan || !weights || !biases || !packed) { set_error("spr_resnet_pack_weights: null pointer"); return SPR_ERR_ARG; }
+  for (size_t i = 0; i < plan->convs.size(); ++i) {
+    const RConv& c = plan->convs[i];
+    if (!weights[i] || !biases[i]) { set_error("spr_resnet_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
+    hipLaunchKernelGGL(rpack_kernel, dim3(256), dim3(kThreads), 0, static_cast<hipStream_t>(stream), weights[i], biases[i],
+                       static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks, i == 0 ? 1 : 0);
+    const int rc = check_launch("rpack_kernel");
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
+}
+
+// four activation buffers (block input, two bottleneck intermediates / the downsample branch, block output), each as
+// large as the largest tensor between layers: the stem's output
+extern "C" size_t spr_resnet_workspace_bytes(const spr_resnet_plan* plan, int64_t n, int32_t in_h, int32_t in_w) {
+  if (!plan || n < 0) return 0;
+  const size_t stem = static_cast<size_t>(n) * ((in_h + 1) / 2) * ((in_w + 1) / 2) * 64;
+  return 4 * align_up(stem * sizeof(float), 256);
+}
+
+template <int KS, int STRIDE>
+static int launch_gemm(const RConv& c, const float* in, int64_t n, int h, int w, const float* pk, const float* res, int nchw,
+                       float* out, hipStream_t s) {
+  const int pad = KS / 2;
+  const int ho = (h + 2 * pad - KS) / STRIDE + 1, wo = (w + 2 * pad - KS) / STRIDE + 1;
+  const long long m = static_cast<long long>(n) * ho * wo;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<KS, STRIDE>), dim3(static_cast<unsigned>((m + kGM - 1) / kGM),
+                     static_cast<unsigned>(c.cout / kGN)), dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, c.cin, c.cout,
+                     pk + c.w_off, pk + c.b_off, res, c.relu, nchw, out);
+  return check_launch("conv_gemm_kernel");
+}
+
+extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                                  int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                                  void* workspace, float* out, spr_stream_t stream) {
+  if (!plan) { set_error("spr_resnet_forward: null plan"); return SPR_ERR_ARG; }
+  if (n < 0 || n > 65535 || in_h < 32 || in_w < 32 || (in_channels != 1 && in_channels != 3)) {
+    set_error("spr_resnet_forward: bad sizes (n in [0, 65535], images at least 32 x 32, in_channels 1 or 3)");
+    return SPR_ERR_ARG;
+  }
+  if (n == 0) return SPR_OK;
+  if (!images || !mean3 || !inv_std3 || !packed || !out || !workspace) { set_error("spr_resnet_forward: null pointer"); return SPR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* pk = static_cast<const float*>(packed);
+  const size_t quarter = spr_resnet_workspace_bytes(plan, n, in_h, in_w) / 4;
+  float* buf[4];
+  for (int i = 0; i < 4; ++i) buf[i] = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + i * quarter);
+  // stem + max pool
+  int h = (in_h + 1) / 2, w = (in_w + 1) / 2;
+  {
+    const RConv& c = plan->convs[0];
+    const unsigned tiles = static_cast<unsigned>(ceil_div(h, 8) * ceil_div(w, 8));
+    hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w,
+                       in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + c.w_off,
+                       pk + c.b_off, buf[1]);
+    int rc = check_launch("stem_kernel");
+    if (rc != SPR_OK) return rc;
+    const int hp = (h + 1) / 2, wp = (w + 1) / 2;
+    const size_t total = static_cast<size_t>(n) * hp * wp * 64;
+    hipLaunchKernelGGL(maxpool3_kernel, dim3(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16))),
+                       dim3(kThreads), 0, s, buf[1], h, w, 64, buf[0], total);
+    rc = check_launch("maxpool3_kernel");
+    if (rc != SPR_OK) return rc;
+    h = hp; w = wp;
+  }
+  // bottlenecks: x = buf[0]
+  float* x = buf[0];
+  float* t1 = buf[1];
+  float* t2 = buf[2];
+  float* y = buf[3];
+  size_t i = 1;
+  while (i < plan->convs.size()) {
+    const RConv& c1 = plan->convs[i];
+    const RConv& c2 = plan->convs[i + 1];
+    const RConv& c3 = plan->convs[i + 2];
+    const bool down = c3.res == 2;
+    const bool last = i + (down ? 4 : 3) == plan->convs.size();
+    const int ho = c2.stride == 2 ? (h + 1) / 2 : h, wo = c2.stride == 2 ? (w + 1) / 2 : w;
+    int rc = launch_gemm<1, 1>(c1, x, n, h, w, pk, nullptr, 0, t1, s);
+    if (rc != SPR_OK) return rc;
+    rc = c2.stride == 2 ? launch_gemm<3, 2>(c2, t1, n, h, w, pk, nullptr, 0, t2, s)
+                        : launch_gemm<3, 1>(c2, t1, n, h, w, pk, nullptr, 0, t2, s);
+    if (rc != SPR_OK) return rc;
+    const float* resid = x;
+    if (down) {
+      const RConv& cd = plan->convs[i + 3];
+      rc = cd.stride == 2 ? launch_gemm<1, 2>(cd, x, n, h, w, pk, nullptr, 0, t1, s)
+                          : launch_gemm<1, 1>(cd, x, n, h, w, pk, nullptr, 0, t1, s);
+      if (rc != SPR_OK) return rc;
+      resid = t1;
+    }
+    float* dst = last ? out : y;
+    rc = launch_gemm<1, 1>(c3, t2, n, ho, wo, pk, resid, last ? 1 : 0, dst, s);
+    if (rc != SPR_OK) return rc;
+    h = ho; w = wo;
+    float* old = x;
+    x = y;
+    y = old;
+    i += down ? 4 : 3;
+  }
+  return SPR_OK;
+}

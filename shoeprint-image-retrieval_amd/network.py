@@ -11,8 +11,10 @@ library's ``spr_vgg16_forward`` (implicit-GEMM 3x3 convolutions on the fp32 matr
 ReLU / max-pool fused, pre-processing fused into the first layer) and — unlike the reference's one
 image per launch (network.py:228) — runs whole batches; ``extract_device`` keeps the features in HBM
 for the scorer.  Unknown ``model.type`` raises ``LookupError("Model string not found")`` as the
-reference does (network.py:180-182); the reference's other backbones (VGG19, EfficientNet*, DenseNet)
-are not built and raise ``NotImplementedError``.
+reference does (network.py:180-182); the reference's EfficientNet* / DenseNet backbones are not built
+and raise ``NotImplementedError``.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
+layer3 extractor, the reference has none): torchvision's resnet50 cut after ``block`` of its top-level children
+[conv1, bn1, relu, maxpool, layer1, layer2, layer3], block = 5 / 6 / 7, ImageNet mean / std.
 
 Weights: torchvision downloads ``IMAGENET1K_FEATURES`` by name (network.py:126), impossible offline.
 ``config["mi355x"]["weights"]`` may name a local state dict (``features.N.weight/bias``, loaded with
@@ -38,6 +40,9 @@ BN_EPS = 1e-5                                                # torch.nn.BatchNor
 # model.type -> (spr_vgg_arch, mean, std): the plain-VGG branches of network.py:121-139
 _VGG_MODELS = {"VGG16": (0, VGG16_MEAN, VGG16_STD), "VGG19": (1, IMAGENET_MEAN, IMAGENET_STD),
                "VGG19_BN": (2, IMAGENET_MEAN, IMAGENET_STD)}
+# BUILD-DEFINED (BASELINE.json config 3; the reference has no ResNet branch): torchvision's resnet50 cut after `block` of its
+# top-level children [conv1, bn1, relu, maxpool, layer1, layer2, layer3] - block 5 / 6 / 7 - with the default transforms
+_RESNET_MODELS = {"ResNet50": (IMAGENET_MEAN, IMAGENET_STD)}
 _REFERENCE_MODELS = {"EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
                      "EfficientNet_B5", "EfficientNet_B7", "EfficientNetV2_S", "EfficientNetV2_M", "EfficientNetV2_L",
                      "DenseNet_201"}
@@ -54,13 +59,17 @@ class Model:
         self.clahe_clip_limit = float(model_cfg.get("clahe_clip_limit", 2.0))
         self.clahe_tile_grid_size = tuple(model_cfg.get("clahe_tile_grid_size", (8, 8)))
         model_str = model_cfg["type"]
-        if model_str not in _VGG_MODELS:
+        self.resnet = model_str in _RESNET_MODELS
+        if model_str not in _VGG_MODELS and not self.resnet:
             if model_str in _REFERENCE_MODELS:
                 raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); "
                                           f"use one of {sorted(_VGG_MODELS)}")
             raise LookupError("Model string not found")  # network.py:180-182
         self.model_str = model_str
-        self.arch, self.mean, self.std = _VGG_MODELS[model_str]
+        if self.resnet:
+            self.arch, (self.mean, self.std) = -1, _RESNET_MODELS[model_str]
+        else:
+            self.arch, self.mean, self.std = _VGG_MODELS[model_str]
         self.block = int(block)
         self.batch_size = int(batch_size)
         self.lib = library or _lib.load_library()
@@ -70,12 +79,83 @@ class Model:
             device = TorchDevice()
         self.dev = device
         handle = C.c_void_p()
+        if self.resnet:
+            self.lib.check(self.lib.spr_resnet_plan_create(self.block, C.byref(handle)))
+            self.handle = handle
+            self.n_convs = self.lib.spr_resnet_num_convs(handle)
+            if parameters is None:
+                parameters = self._load_resnet_parameters(config)
+            self._set_resnet_parameters(parameters)
+            return
         self.lib.check(self.lib.spr_vgg_plan_create(self.arch, self.block, C.byref(handle)))
         self.handle = handle
         self.n_convs = self.lib.spr_vgg16_num_convs(handle)
         if parameters is None:
             parameters = self._load_parameters(config)
         self._set_parameters(parameters)
+
+    # ------------------------------------------------------------------ ResNet50 (build-defined)
+    def conv_specs(self) -> list[tuple[int, int, int, int, int]]:
+        """(cin, cout, ksize, stride, role) of every convolution in torchvision's module order."""
+        out = []
+        for i in range(self.n_convs):
+            v = [C.c_int32() for _ in range(5)]
+            self.lib.check(self.lib.spr_resnet_conv_shape(self.handle, i, *[C.byref(t) for t in v]))
+            out.append(tuple(t.value for t in v))
+        return out
+
+    def _resnet_state_names(self) -> list[tuple[str, str]]:
+        """(convolution, BatchNorm) module names in a torchvision resnet50 state dict, in conv_specs order."""
+        names = [("conv1", "bn1")]
+        for layer in range(self.block - 4):
+            for b in range((3, 4, 6)[layer]):
+                pre = f"layer{layer + 1}.{b}"
+                names += [(f"{pre}.conv1", f"{pre}.bn1"), (f"{pre}.conv2", f"{pre}.bn2"), (f"{pre}.conv3", f"{pre}.bn3")]
+                if b == 0:
+                    names.append((f"{pre}.downsample.0", f"{pre}.downsample.1"))
+        return names
+
+    def _load_resnet_parameters(self, config):
+        global _warned
+        path = config.get("mi355x", {}).get("weights", "")
+        if path:
+            import torch
+
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            params = []
+            for conv, bn in self._resnet_state_names():
+                w = state[f"{conv}.weight"].float().numpy()
+                b = state[f"{conv}.bias"].float().numpy() if f"{conv}.bias" in state else np.zeros(w.shape[0], np.float32)
+                params.append((w, b) + tuple(state[f"{bn}.{n}"].float().numpy()
+                                             for n in ("weight", "bias", "running_mean", "running_var")))
+            return params
+        if not _warned:
+            print(f"shoeprint_image_retrieval_amd: no [mi355x].weights given — using seeded synthetic {self.model_str} "
+                  "weights (pretrained ImageNet weights cannot be downloaded offline)", file=sys.stderr)
+            _warned = True
+        return synth.resnet_parameters(1234, self.conv_specs())
+
+    def _set_resnet_parameters(self, parameters):
+        specs = self.conv_specs()
+        if len(parameters) < len(specs):
+            raise ValueError(f"{len(specs)} convolutions need parameters, got {len(parameters)}")
+        dev = self.dev
+        self._w_dev, self._b_dev = [], []
+        for (cin, cout, ks, _stride, _role), p in zip(specs, parameters):
+            if len(p) != 6:
+                raise ValueError("every ResNet convolution needs (w, b, gamma, beta, running_mean, running_var)")
+            w, b, gamma, beta, mu, var = (np.asarray(t, dtype=np.float32) for t in p)
+            if w.shape != (cout, cin, ks, ks) or b.shape != (cout,):
+                raise ValueError(f"parameter shape {w.shape}/{b.shape} does not match conv {cin}->{cout} {ks}x{ks}")
+            scale = gamma / np.sqrt(var + np.float32(BN_EPS))  # eval-mode BatchNorm folded into the convolution
+            self._w_dev.append(dev.to_device(np.ascontiguousarray(w * scale[:, None, None, None])))
+            self._b_dev.append(dev.to_device(np.ascontiguousarray((b - mu) * scale + beta)))
+        n = len(specs)
+        wp = (C.c_void_p * n)(*[dev.ptr(t) for t in self._w_dev])
+        bp = (C.c_void_p * n)(*[dev.ptr(t) for t in self._b_dev])
+        self.packed = dev.empty_bytes(max(16, self.lib.spr_resnet_packed_bytes(self.handle)))
+        self.lib.check(self.lib.spr_resnet_pack_weights(self.handle, wp, bp, dev.ptr(self.packed), dev.stream()))
+        dev.synchronize()
 
     # ------------------------------------------------------------------ parameters
     def conv_shapes(self) -> list[tuple[int, int]]:
@@ -148,7 +228,8 @@ class Model:
     # ------------------------------------------------------------------ shapes
     def output_shape(self, in_h: int, in_w: int) -> tuple[int, int, int]:
         c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
-        self.lib.check(self.lib.spr_vgg16_output_shape(self.handle, in_h, in_w, C.byref(c), C.byref(h), C.byref(w)))
+        fn = self.lib.spr_resnet_output_shape if self.resnet else self.lib.spr_vgg16_output_shape
+        self.lib.check(fn(self.handle, in_h, in_w, C.byref(c), C.byref(h), C.byref(w)))
         return c.value, h.value, w.value
 
     # ------------------------------------------------------------------ forward
@@ -159,10 +240,12 @@ class Model:
         n, h, w = shape[0], shape[1], shape[2]
         c, oh, ow = self.output_shape(h, w)
         out = dev.empty((n, c, oh, ow), np.float32)
-        ws = dev.empty_bytes(max(16, self.lib.spr_vgg16_workspace_bytes(self.handle, n, h, w)))
+        ws_fn = self.lib.spr_resnet_workspace_bytes if self.resnet else self.lib.spr_vgg16_workspace_bytes
+        fwd = self.lib.spr_resnet_forward if self.resnet else self.lib.spr_vgg16_forward
+        ws = dev.empty_bytes(max(16, ws_fn(self.handle, n, h, w)))
         mean = (C.c_float * 3)(*self.mean)
         inv_std = (C.c_float * 3)(*[np.float32(1.0) / np.float32(s) for s in self.std])
-        self.lib.check(self.lib.spr_vgg16_forward(self.handle, dev.ptr(images_dev), n, h, w, in_channels, mean, inv_std,
+        self.lib.check(fwd(self.handle, dev.ptr(images_dev), n, h, w, in_channels, mean, inv_std,
                                                   dev.ptr(self.packed), dev.ptr(ws), dev.ptr(out), dev.stream()))
         return out
 
@@ -212,7 +295,7 @@ class Model:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.spr_vgg16_plan_destroy(self.handle)
+            (self.lib.spr_resnet_plan_destroy if self.resnet else self.lib.spr_vgg16_plan_destroy)(self.handle)
             self.handle = None
 
     def __del__(self):  # pragma: no cover

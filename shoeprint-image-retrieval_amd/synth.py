@@ -152,6 +152,27 @@ def vgg_parameters(seed: int, conv_shapes, bn_flags=None):
     return out
 
 
+def resnet_parameters(seed: int, conv_specs):
+    """Seeded parameters of the build-defined ResNet50 extractor: for every (cin, cout, ksize, stride, role) a He-normal
+    convolution weight [cout,cin,k,k], a small bias and BatchNorm2d (gamma, beta, running mean, running variance).  The
+    last BatchNorm of a bottleneck (role 3) gets gamma ~ 0.5 so that activations stay O(1) through sixteen residual sums."""
+    out = []
+    for i, (cin, cout, ks, _stride, role) in enumerate(conv_specs):
+        n = cout * cin * ks * ks
+        w = irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 5000 + 8 * i), np.arange(n, dtype=np.int64)).astype(np.float32)
+        w = (w * np.float32(np.sqrt(2.0 / (cin * ks * ks)) / 37837.0)).reshape(cout, cin, ks, ks)
+        idx = np.arange(cout, dtype=np.int64)
+        u = [irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 5000 + 8 * i + 1 + k), idx).astype(np.float32) / np.float32(37837.0)
+             for k in range(5)]
+        b = np.float32(0.05) * u[0]
+        gamma = (np.float32(0.5) if role == 3 else np.float32(1.0)) * (np.float32(1.0) + np.float32(0.1) * np.clip(u[1], -3, 3))
+        beta = np.float32(0.05) * u[2]
+        mean = np.float32(0.1) * u[3]
+        var = np.float32(1.0) + np.float32(0.4) * np.tanh(u[4])
+        out.append(tuple(np.ascontiguousarray(t, dtype=np.float32) for t in (w, b, gamma, beta, mean, var)))
+    return out
+
+
 def bfloat16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bfloat16 bit patterns (uint16), round to nearest even — the storage form the scorer
     accepts for bf16 features (numpy has no bfloat16 type)."""

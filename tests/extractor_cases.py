@@ -4,7 +4,7 @@ reference, see its header).  Tolerance: 2e-5 of the largest activation (float32 
 
 import numpy as np
 
-from oracle import clahe_oracle, ncc_oracle, vgg_oracle
+from oracle import clahe_oracle, ncc_oracle, resnet_oracle, vgg_oracle
 from shoeprint_image_retrieval_amd import network, similarity, synth
 
 CFG = {"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]},
@@ -42,6 +42,26 @@ def check_other_vgg(arch, block, hw, device, lib):
         ref = vgg_oracle.get_feature_maps(imgs[i], block, params, arch)
         assert got[i].shape == ref.shape
         np.testing.assert_allclose(got[i], ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+    m.close()
+
+
+def check_resnet50(block, hw, device, lib, n_images=2, tol=5e-5):
+    """The build-defined ResNet50 extractor (BASELINE config 3) against the torch-CPU oracle with the same seeded
+    parameters; parity unpinned by the reference (it has no ResNet).  Tolerance: relative to the largest activation."""
+    cfg = {"model": dict(CFG["model"], type="ResNet50"), "comparison": CFG["comparison"]}
+    m = network.Model(cfg, block, device=device, library=lib)
+    assert m.conv_specs() == resnet_oracle.conv_specs(block)
+    params = synth.resnet_parameters(1234, m.conv_specs())
+    imgs = np.stack([synth.shoeprint_image(8, i, *hw) for i in range(n_images)])
+    got = device.to_host(m.extract_device(device.to_device(imgs)))
+    assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    for i in range(n_images):
+        ref = resnet_oracle.get_feature_maps(imgs[i], block, params)
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+    fm = m.get_feature_maps(imgs[0])
+    ref = resnet_oracle.get_feature_maps(clahe_oracle.clahe(imgs[0], 2.0, (8, 8)), block, params)
+    np.testing.assert_allclose(fm, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
     m.close()
 
 

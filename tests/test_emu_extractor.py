@@ -27,6 +27,12 @@ def test_emu_other_vgg_backbones(arch, block, hw):
     ec.check_other_vgg(arch, block, hw, HostDevice(), emu_library())
 
 
+def test_emu_resnet50_layer1():
+    """The build-defined ResNet50 extractor under emulation: stem, max pool, the three bottlenecks of layer1 (1x1 and 3x3
+    implicit GEMMs, downsample branch, residual sums) on a 40x36 image - odd-sized maps after the strided layers."""
+    ec.check_resnet50(5, (40, 36), HostDevice(), emu_library(), n_images=1)
+
+
 def test_emu_reference_surface():
     ec.check_reference_surface(HostDevice(), emu_library())
 

@@ -217,6 +217,15 @@ def test_other_vgg_backbones(arch, block, hw, torch_dev, lib):
     ec.check_other_vgg(arch, block, hw, torch_dev, lib)
 
 
+@pytest.mark.parametrize("block,hw", [(5, (64, 48)), (6, (100, 72)), (7, (512, 256))])
+def test_resnet50_extractor(torch_dev, lib, block, hw):
+    """Build-defined ResNet50 (BASELINE config 3) through layer1 / layer2 / layer3 - the last at the full 512x256 print,
+    [1024, 32, 16] out - vs torch-CPU with the same seeded parameters."""
+    import extractor_cases as ec
+
+    ec.check_resnet50(block, hw, torch_dev, lib, n_images=1 if block == 7 else 2)
+
+
 def test_extractor_reference_surface(torch_dev, lib):
     import extractor_cases as ec
 
