@@ -219,6 +219,16 @@ int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, in
                       int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
                       void* workspace, float* out, spr_stream_t stream);
 
+/* As spr_vgg16_forward, and convolution tap_convs[t] (ordinal among the plan's convolutions, not the first one) also
+ * writes its activation - after bias / BatchNorm / ReLU, BEFORE any max-pool fused behind it - to tap_out[t] as float32
+ * NCHW [n, cout, h, w] of that layer.  One pass of the extractor then feeds a multi-layer score (BASELINE config 5:
+ * conv3_3 + conv4_3 + conv5_3 = convolutions 6, 9 and 12 of features[:30]; the reference runs one block per cluster,
+ * run.py:20). */
+int spr_vgg16_forward_taps(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                           int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                           void* workspace, float* out, int32_t n_taps, const int32_t* tap_convs, float* const* tap_out,
+                           spr_stream_t stream);
+
 /* ------------------------------------------------------------------ ResNet50 extractor (build-defined)
  * BASELINE.json config 3 asks for "ResNet50 layer3 summed maps"; the reference has no ResNet branch (network.py:121-182)
  * and its truncation rule `list(model.features.children())[:block]` (network.py:185) has no `.features` to act on there.

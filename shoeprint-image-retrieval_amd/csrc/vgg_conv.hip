@@ -143,7 +143,8 @@ conv_first_kernel(const uint8_t* __restrict__ images, int H, int W, int in_chann
 // grid = (tiles, cout/64, n images)
 __global__ void __launch_bounds__(kThreads, 2)
 conv_mfma_kernel(const float* __restrict__ in, int H, int W, int cin, int cout, const float* __restrict__ wts,
-                 const float* __restrict__ bias, int relu, int pool, int nchw, float* __restrict__ out) {
+                 const float* __restrict__ bias, int relu, int pool, int nchw, float* __restrict__ out,
+                 float* __restrict__ tap) {
   unsigned char* lds = dyn_lds();
   float* patch = reinterpret_cast<float*>(lds);                 // [18*18][kCS]
   float* wl = patch + kPatch * kPatch * kCS;                    // [9*64][kCS]
@@ -244,6 +245,15 @@ conv_mfma_kernel(const float* __restrict__ in, int H, int W, int cin, int cout, 
         const float t = acc[i][j][jj] + bv;
         v[i][jj] = relu ? fmaxf(t, 0.0f) : t;
       }
+    if (tap) {  // a feature tap (multi-layer scoring): this layer's activation before the pool, NCHW float32
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int y = y0 + 4 * wave + i, x = x0 + 4 * q + jj;
+          if (y < H && x < W) tap[((img * cout + ch) * H + y) * static_cast<size_t>(W) + x] = v[i][jj];
+        }
+    }
     if (pool) {
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2)
@@ -427,17 +437,26 @@ extern "C" size_t spr_vgg16_workspace_bytes(const spr_vgg16_plan* plan, int64_t 
   return 2 * align_up(biggest * sizeof(float), 256);
 }
 
-extern "C" int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
-                                 int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
-                                 void* workspace, float* out, spr_stream_t stream) {
-  if (!plan) { set_error("spr_vgg16_forward: null plan"); return SPR_ERR_ARG; }
+static int vgg_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                       int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed, void* workspace,
+                       float* out, int32_t n_taps, const int32_t* tap_convs, float* const* tap_out, spr_stream_t stream,
+                       const char* who) {
+  if (!plan) { set_error("%s: null plan", who); return SPR_ERR_ARG; }
   if (n < 0 || n > 65535 || in_h < 1 || in_w < 1 || (in_channels != 1 && in_channels != 3)) {
-    set_error("spr_vgg16_forward: bad sizes (n in [0, 65535], in_channels 1 or 3)");
+    set_error("%s: bad sizes (n in [0, 65535], in_channels 1 or 3)", who);
     return SPR_ERR_ARG;
+  }
+  if (n_taps < 0 || (n_taps > 0 && (!tap_convs || !tap_out))) { set_error("%s: bad taps", who); return SPR_ERR_ARG; }
+  for (int t = 0; t < n_taps; ++t) {
+    if (tap_convs[t] < 1 || tap_convs[t] >= static_cast<int>(plan->stages.size()) || !tap_out[t]) {
+      set_error("%s: tap %d names convolution %d: taps are convolutions 1 .. %zu (not the first) and need a buffer", who, t,
+                tap_convs[t], plan->stages.size() - 1);
+      return SPR_ERR_ARG;
+    }
   }
   if (n == 0) return SPR_OK;
   if (!images || !mean3 || !inv_std3 || !packed || !out || (plan->stages.size() > 1 && !workspace)) {
-    set_error("spr_vgg16_forward: null pointer");
+    set_error("%s: null pointer", who);
     return SPR_ERR_ARG;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -453,6 +472,9 @@ extern "C" int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, in
     const Stage& st = plan->stages[i];
     const bool last = i + 1 == plan->stages.size();
     float* dst = last ? out : buf[i & 1];
+    float* tap = nullptr;
+    for (int t = 0; t < n_taps; ++t)
+      if (tap_convs[t] == static_cast<int>(i)) tap = tap_out[t];
     const unsigned tiles = static_cast<unsigned>(ceil_div(h, kTile) * ceil_div(w, kTile));
     if (i == 0) {
       hipLaunchKernelGGL(conv_first_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, h, w,
@@ -463,7 +485,7 @@ extern "C" int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, in
     } else {
       hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, static_cast<unsigned>(st.cout / kTN), static_cast<unsigned>(n)),
                          dim3(kThreads), kConvLds, s, cur, h, w, st.cin, st.cout, pk + st.w_off, pk + st.b_off, st.relu,
-                         st.pool, last ? 1 : 0, dst);
+                         st.pool, last ? 1 : 0, dst, tap);
       const int rc = check_launch("conv_mfma_kernel");
       if (rc != SPR_OK) return rc;
     }
@@ -471,4 +493,19 @@ extern "C" int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, in
     cur = dst;
   }
   return SPR_OK;
+}
+
+extern "C" int spr_vgg16_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                                 int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                                 void* workspace, float* out, spr_stream_t stream) {
+  return vgg_forward(plan, images, n, in_h, in_w, in_channels, mean3, inv_std3, packed, workspace, out, 0, nullptr, nullptr,
+                     stream, "spr_vgg16_forward");
+}
+
+extern "C" int spr_vgg16_forward_taps(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                                      int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                                      void* workspace, float* out, int32_t n_taps, const int32_t* tap_convs,
+                                      float* const* tap_out, spr_stream_t stream) {
+  return vgg_forward(plan, images, n, in_h, in_w, in_channels, mean3, inv_std3, packed, workspace, out, n_taps, tap_convs,
+                     tap_out, stream, "spr_vgg16_forward_taps");
 }

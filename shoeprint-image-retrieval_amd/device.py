@@ -80,6 +80,33 @@ class TorchDevice:
     def synchronize(self) -> None:
         self.torch.cuda.synchronize(self.device)
 
+    # -- streams (multi-layer pipeline: extractor and per-layer scoring chains overlap) ----------------
+    def new_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
+    def current(self):
+        return self.torch.cuda.current_stream(self.device)
+
+    def use(self, stream):
+        """Context manager: work enqueued inside goes to ``stream`` (the C-ABI calls take torch's current stream)."""
+        return self.torch.cuda.stream(stream)
+
+    def record_event(self, stream):
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def wait_event(self, stream, event) -> None:
+        stream.wait_event(event)
+
+    def wait_stream(self, waiter, waited) -> None:
+        waiter.wait_stream(waited)
+
+    def record_stream(self, buf, stream) -> None:
+        """``buf`` (allocated on another stream) is used by work enqueued on ``stream``: its memory must not be handed out
+        again before that work has run."""
+        buf.record_stream(stream)
+
     def free_bytes(self) -> int:
         free, _total = self.torch.cuda.mem_get_info(self.device)
         return int(free)

@@ -249,6 +249,55 @@ class Model:
                                                   dev.ptr(self.packed), dev.ptr(ws), dev.ptr(out), dev.stream()))
         return out
 
+    def extract_taps_device(self, images_dev, tap_features, in_channels: int = 1):
+        """One pass of the (plain VGG) extractor that also returns the activations at ``tap_features`` - slice ends into
+        ``model.features`` like ``block``, each just behind a ReLU (16 = conv3_3, 23 = conv4_3, 30 = conv5_3 for VGG16) -
+        as float32 device arrays [N, C_l, h_l, w_l], in that order; a tap equal to ``block`` is the network's output.
+        Multi-layer scoring (BASELINE config 5) feeds on this: the reference would run the extractor once per block."""
+        if self.resnet:
+            raise NotImplementedError("feature taps are built for the plain VGG backbones")
+        dev = self.dev
+        n, h, w = dev.shape(images_dev)[:3]
+        info = self.conv_info()          # (index in model.features, BatchNorm inside) per convolution
+        shapes = self.conv_shapes()
+        c, oh, ow = self.output_shape(h, w)
+        out = dev.empty((n, c, oh, ow), np.float32)
+        taps, tap_convs, tap_bufs = [], [], []
+        for t in tap_features:
+            if t == self.block:
+                taps.append(out)
+                continue
+            # the convolution whose ReLU ends the slice features[:t]
+            ordinal = [i for i, (k, bn) in enumerate(info) if k + (2 if bn else 1) == t - 1]
+            if not ordinal or ordinal[0] == 0:
+                raise ValueError(f"tap {t}: not the ReLU behind one of the convolutions 1.. of features[:{self.block}]")
+            i = ordinal[0]
+            # spatial size of convolution i's output = image size halved once per max-pool in front of it
+            pools = sum(1 for j in range(i) if self._stage_pool(j))
+            hh, ww = h >> pools, w >> pools
+            buf = dev.empty((n, shapes[i][1], hh, ww), np.float32)
+            taps.append(buf)
+            tap_convs.append(i)
+            tap_bufs.append(buf)
+        ws = dev.empty_bytes(max(16, self.lib.spr_vgg16_workspace_bytes(self.handle, n, h, w)))
+        mean = (C.c_float * 3)(*self.mean)
+        inv_std = (C.c_float * 3)(*[np.float32(1.0) / np.float32(s) for s in self.std])
+        nt = len(tap_convs)
+        self.lib.check(self.lib.spr_vgg16_forward_taps(
+            self.handle, dev.ptr(images_dev), n, h, w, in_channels, mean, inv_std, dev.ptr(self.packed), dev.ptr(ws),
+            dev.ptr(out), nt, (C.c_int32 * max(1, nt))(*tap_convs), (C.c_void_p * max(1, nt))(*[dev.ptr(b) for b in tap_bufs]),
+            dev.stream()))
+        return taps
+
+    def _stage_pool(self, i: int) -> bool:
+        """Does a max-pool follow convolution i (and its BatchNorm / ReLU) inside features[:block]?"""
+        info = self.conv_info()
+        k, bn = info[i]
+        pool_at = k + (3 if bn else 2)  # where a pool would sit: behind the ReLU
+        if i + 1 < len(info):
+            return info[i + 1][0] == pool_at + 1  # the next convolution starts right behind a pool, not behind the ReLU
+        return pool_at < self.block
+
     def clahe_device(self, images_dev):
         """CLAHE of a uint8 device batch [N,H,W] (network.py:108-111, 206) — HIP kernels, stays in HBM."""
         dev = self.dev

@@ -50,6 +50,30 @@ class HostDevice:
     def synchronize(self):
         pass
 
+    # streams: the emulation runs every call to completion, so they are all the one host "stream"
+    def new_stream(self):
+        return None
+
+    def current(self):
+        return None
+
+    def use(self, stream):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def record_event(self, stream):
+        return None
+
+    def wait_event(self, stream, event):
+        pass
+
+    def wait_stream(self, waiter, waited):
+        pass
+
+    def record_stream(self, buf, stream):
+        pass
+
     def free_bytes(self) -> int:
         return 8 << 30
 

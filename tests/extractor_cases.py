@@ -65,6 +65,32 @@ def check_resnet50(block, hw, device, lib, n_images=2, tol=5e-5):
     m.close()
 
 
+def check_multi_layer_pipeline(device, lib, scorer, hw=(64, 48), taps=(9, 14, 16), n_gallery=7, n_queries=3, batch=3):
+    """BASELINE config 5 in miniature: one extractor pass with feature taps, per-layer scoring chains on their own
+    streams (gallery in batches, the last one ragged), fusion on the device - against the oracle chain: torch-CPU features
+    of every tapped layer, the NCC oracle per layer, the mean."""
+    from shoeprint_image_retrieval_amd import pipeline
+
+    m = make_model(max(taps), device, lib)
+    params = synth.vgg16_parameters(1234, m.conv_shapes())
+    gallery = np.stack([synth.shoeprint_image(23, g, *hw) for g in range(n_gallery)])
+    rng = np.random.default_rng(5)
+    queries = np.stack([np.clip(np.roll(gallery[q].astype(np.int32), (1, -2), axis=(0, 1)) + rng.normal(0, 20, hw), 0, 255)
+                        .astype(np.uint8) for q in range(n_queries)])
+    pipe = pipeline.MultiLayerPipeline(m, scorer, taps=taps, batch_size=batch)
+    got = device.to_host(pipe.scores_device(device.to_device(queries), device.to_device(gallery)))
+    ref = np.zeros((n_queries, n_gallery), dtype=np.float64)
+    for t in taps:
+        gf = [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), t, params) for im in gallery]
+        qf = [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), t, params) for im in queries]
+        ref += ncc_oracle.similarity_matrix(qf, gf, precise=True).astype(np.float32)
+    ref /= len(taps)
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+    ranks = pipe.ranks(device.to_device(queries), device.to_device(gallery), list(range(n_queries)))
+    np.testing.assert_array_equal(ranks, ncc_oracle.ranks_from_matrix(ref.astype(np.float32), list(range(n_queries))))
+    m.close()
+
+
 def check_reference_surface(device, lib):
     """Model(config, block), get_feature_maps, get_multiple_feature_maps keep the reference's behaviour."""
     m = make_model(5, device, lib, batch_size=2)

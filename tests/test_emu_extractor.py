@@ -33,6 +33,10 @@ def test_emu_resnet50_layer1():
     ec.check_resnet50(5, (40, 36), HostDevice(), emu_library(), n_images=1)
 
 
+def test_emu_multi_layer_pipeline():
+    ec.check_multi_layer_pipeline(HostDevice(), emu_library(), emu_scorer("fft"), hw=(40, 32), n_gallery=5, n_queries=2, batch=2)
+
+
 def test_emu_reference_surface():
     ec.check_reference_surface(HostDevice(), emu_library())
 

@@ -226,6 +226,13 @@ def test_resnet50_extractor(torch_dev, lib, block, hw):
     ec.check_resnet50(block, hw, torch_dev, lib, n_images=1 if block == 7 else 2)
 
 
+def test_multi_layer_pipeline(torch_dev, lib, fft_scorer):
+    """Config 5: conv3_3 + conv4_3 + conv5_3 taps of one VGG16 pass, scored on separate streams, fused on the device."""
+    import extractor_cases as ec
+
+    ec.check_multi_layer_pipeline(torch_dev, lib, fft_scorer, hw=(128, 96), taps=(16, 23, 30), n_gallery=9, n_queries=4, batch=4)
+
+
 def test_extractor_reference_surface(torch_dev, lib):
     import extractor_cases as ec
 
