@@ -229,6 +229,16 @@ int spr_vgg16_forward_taps(spr_vgg16_plan* plan, const uint8_t* images, int64_t 
                            void* workspace, float* out, int32_t n_taps, const int32_t* tap_convs, float* const* tap_out,
                            spr_stream_t stream);
 
+/* ------------------------------------------------------------------ RGB route of CLAHE (network.py:199-204)
+ * The reference equalises a colour image on its L channel: cv2.cvtColor(RGB2LAB) -> CLAHE(L) -> cv2.cvtColor(LAB2RGB).
+ * 8-bit convention (L * 255/100, a + 128, b + 128; sRGB, D65); interleaved uint8 [n_pixels, 3] in and out.  `tables`:
+ * device buffer of spr_color_tables_bytes() bytes filled by the caller (int32: 256 gamma, 3072 cube-root, 9 matrix,
+ * 4096 inverse-gamma entries; shoeprint_image_retrieval_amd/color.py builds them).  Parity with OpenCV itself is
+ * unpinned (no cv2 offline): the kernels are bit-identical to oracle/color_oracle.py. */
+size_t spr_color_tables_bytes(void);
+int spr_rgb_to_lab_u8(const uint8_t* rgb, uint8_t* lab, int64_t n_pixels, const void* tables, spr_stream_t stream);
+int spr_lab_to_rgb_u8(const uint8_t* lab, uint8_t* rgb, int64_t n_pixels, const void* tables, spr_stream_t stream);
+
 /* ------------------------------------------------------------------ ResNet50 extractor (build-defined)
  * BASELINE.json config 3 asks for "ResNet50 layer3 summed maps"; the reference has no ResNet branch (network.py:121-182)
  * and its truncation rule `list(model.features.children())[:block]` (network.py:185) has no `.features` to act on there.

@@ -42,9 +42,12 @@ def conv_shapes(block: int, arch: str = "VGG16"):
 
 
 def get_feature_maps(img: np.ndarray, block: int, parameters, arch: str = "VGG16") -> np.ndarray:
-    """uint8 [H,W] (already CLAHE'd) -> float32 [C,h,w].  ``parameters[i]`` = (w, b) or, for a convolution whose
+    """uint8 [H,W] or RGB [H,W,3] (already CLAHE'd) -> float32 [C,h,w].  ``parameters[i]`` = (w, b) or, for a convolution whose
     BatchNorm2d is part of the truncation, (w, b, gamma, beta, running_mean, running_var)."""
-    x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None].repeat(3, 1, 1)  # ToTensor + repeat
+    if img.ndim == 3:  # RGB [H,W,3]: transform_rgb = ToTensor + Normalize (network.py:74-87)
+        x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0))
+    else:
+        x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None].repeat(3, 1, 1)  # ToTensor + repeat
     mean = torch.tensor(ARCHS[arch][2], dtype=torch.float32)[:, None, None]
     std = torch.tensor(ARCHS[arch][3], dtype=torch.float32)[:, None, None]
     x = ((x - mean) / std)[None]

@@ -60,6 +60,9 @@ SIGNATURES = {
     "spr_resample_axis": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "spr_clahe_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "spr_clahe_u8": (C.c_int, [_VP, _VP, _I64, _I32, _I32, C.c_float, _I32, _I32, _VP, _VP]),
+    "spr_color_tables_bytes": (_SZ, []),
+    "spr_rgb_to_lab_u8": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "spr_lab_to_rgb_u8": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "spr_vgg_plan_create": (C.c_int, [_I32, _I32, C.POINTER(_VP)]),
     "spr_vgg_conv_info": (C.c_int, [_VP, _I32, C.POINTER(_I32), C.POINTER(_I32)]),
     "spr_vgg16_plan_create": (C.c_int, [_I32, C.POINTER(_VP)]),

@@ -59,6 +59,13 @@ class TorchDevice:
             out[k].copy_(self.torch.from_numpy(np.ascontiguousarray(it, dtype=np.float32)))
         return out
 
+    def channel(self, buf, k: int):
+        """Contiguous copy of plane k of an interleaved [..., C] buffer."""
+        return buf[..., k].contiguous()
+
+    def set_channel(self, buf, k: int, plane) -> None:
+        buf[..., k].copy_(plane)
+
     def astype_storage(self, buf, storage: str):
         """The float32 batch in its HBM storage type ("float32" | "float16" | "bfloat16"); the kernels read all three."""
         t = {"float32": self.torch.float32, "float16": self.torch.float16, "bfloat16": self.torch.bfloat16}[storage]

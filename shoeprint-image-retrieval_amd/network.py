@@ -299,9 +299,27 @@ class Model:
         return pool_at < self.block
 
     def clahe_device(self, images_dev):
-        """CLAHE of a uint8 device batch [N,H,W] (network.py:108-111, 206) — HIP kernels, stays in HBM."""
+        """CLAHE of a uint8 device batch (network.py:108-111, 197-208) - HIP kernels, stays in HBM.  [N,H,W]: on the
+        image; [N,H,W,3] (RGB): on the L channel of its 8-bit L*a*b* form and back (network.py:199-204)."""
         dev = self.dev
-        n, h, w = dev.shape(images_dev)
+        shape = dev.shape(images_dev)
+        if len(shape) == 4:
+            if shape[3] != 3:
+                raise ValueError("colour images must be [N, H, W, 3] (RGB)")
+            n, h, w = shape[:3]
+            if getattr(self, "_color_tables", None) is None:
+                from . import color
+
+                self._color_tables = dev.to_device(color.tables())
+            lab = dev.empty((n, h, w, 3), np.uint8)
+            self.lib.check(self.lib.spr_rgb_to_lab_u8(dev.ptr(images_dev), dev.ptr(lab), n * h * w, dev.ptr(self._color_tables),
+                                                      dev.stream()))
+            dev.set_channel(lab, 0, self.clahe_device(dev.channel(lab, 0)))
+            rgb = dev.empty((n, h, w, 3), np.uint8)
+            self.lib.check(self.lib.spr_lab_to_rgb_u8(dev.ptr(lab), dev.ptr(rgb), n * h * w, dev.ptr(self._color_tables),
+                                                      dev.stream()))
+            return rgb
+        n, h, w = shape
         tx, ty = int(self.clahe_tile_grid_size[0]), int(self.clahe_tile_grid_size[1])
         out = dev.empty((n, h, w), np.uint8)
         ws = dev.empty_bytes(max(16, self.lib.spr_clahe_workspace_bytes(n, tx, ty)))
@@ -310,9 +328,7 @@ class Model:
         return out
 
     def _clahe(self, img: np.ndarray) -> np.ndarray:
-        """CLAHE before the network (network.py:197-208); grey images only (the LAB route for RGB is not built)."""
-        if img.ndim == 3:
-            raise NotImplementedError("CLAHE of RGB images (RGB->LAB->CLAHE(L)->RGB, network.py:199-204) is not built")
+        """CLAHE before the network (network.py:197-208): grey [H,W] or RGB [H,W,3]."""
         batch = self.dev.to_device(np.ascontiguousarray(img, dtype=np.uint8)[None])
         return self.dev.to_host(self.clahe_device(batch))[0]
 
@@ -331,10 +347,11 @@ class Model:
         for shape, idx in groups.items():
             for start in range(0, len(idx), self.batch_size):
                 part = idx[start:start + self.batch_size]
-                if len(shape) != 2:
-                    raise NotImplementedError("RGB images (network.py:199-204, transform_rgb) are not built: grey [H,W] only")
+                if len(shape) not in (2, 3) or (len(shape) == 3 and shape[2] != 3):
+                    raise ValueError("images must be grey [H,W] or RGB [H,W,3] uint8 arrays")
+                # grey: transform (repeat to three planes); RGB: transform_rgb (network.py:236-241, 60-87)
                 batch = self.dev.to_device(np.stack([np.ascontiguousarray(images[i], dtype=np.uint8) for i in part]))
-                feats = self.dev.to_host(self.extract_device(self.clahe_device(batch), in_channels=1))
+                feats = self.dev.to_host(self.extract_device(self.clahe_device(batch), in_channels=3 if len(shape) == 3 else 1))
                 for k, i in enumerate(part):
                     results[i] = np.ascontiguousarray(feats[k])
                 done += len(part)

@@ -26,6 +26,12 @@ class HostDevice:
     def stack_to_device(self, items):
         return np.ascontiguousarray(np.stack([np.asarray(i, dtype=np.float32) for i in items]))
 
+    def channel(self, buf, k):
+        return np.ascontiguousarray(buf[..., k])
+
+    def set_channel(self, buf, k, plane):
+        buf[..., k] = plane
+
     def astype_storage(self, buf, storage: str):
         if storage == "float32":
             return buf

@@ -4,7 +4,7 @@ reference, see its header).  Tolerance: 2e-5 of the largest activation (float32 
 
 import numpy as np
 
-from oracle import clahe_oracle, ncc_oracle, resnet_oracle, vgg_oracle
+from oracle import clahe_oracle, color_oracle, ncc_oracle, resnet_oracle, vgg_oracle
 from shoeprint_image_retrieval_amd import network, similarity, synth
 
 CFG = {"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]},
@@ -88,6 +88,32 @@ def check_multi_layer_pipeline(device, lib, scorer, hw=(64, 48), taps=(9, 14, 16
     np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
     ranks = pipe.ranks(device.to_device(queries), device.to_device(gallery), list(range(n_queries)))
     np.testing.assert_array_equal(ranks, ncc_oracle.ranks_from_matrix(ref.astype(np.float32), list(range(n_queries))))
+    m.close()
+
+
+def check_rgb_route(device, lib, hw=(40, 32), block=5):
+    """RGB images (network.py:199-204, 74-87): RGB -> L*a*b* -> CLAHE(L) -> RGB bit for bit against the oracle's
+    restatement, round-trip sanity of the colour transform, and the features of an RGB image (transform_rgb: three
+    distinct input planes) against the torch-CPU oracle."""
+    rng = np.random.default_rng(11)
+    m = make_model(block, device, lib)
+    params = synth.vgg16_parameters(1234, m.conv_shapes())
+    base = np.stack([synth.shoeprint_image(31, k, *hw) for k in range(3)], axis=-1)      # three decorrelated planes
+    imgs = [base, rng.integers(0, 256, size=hw + (3,), dtype=np.uint8), np.full(hw + (3,), 200, np.uint8)]
+    for im in imgs:
+        got = m._clahe(im)
+        want = color_oracle.clahe_rgb(im, 2.0, (8, 8))
+        np.testing.assert_array_equal(got, want)
+    # the colour transform alone: every grey level maps to a = b = 128 and back to itself within one level
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    lab = color_oracle.rgb_to_lab(grey)
+    assert np.all(np.abs(lab[..., 1:].astype(int) - 128) <= 1) and np.all(np.diff(lab[0, :, 0].astype(int)) >= 0)
+    assert np.abs(color_oracle.lab_to_rgb(lab).astype(int) - grey).max() <= 2
+    fm = m.get_multiple_feature_maps([imgs[0], imgs[1][:, :, 0].copy()], progress=False)
+    ref_rgb = vgg_oracle.get_feature_maps(color_oracle.clahe_rgb(imgs[0], 2.0, (8, 8)), block, params)
+    ref_grey = vgg_oracle.get_feature_maps(clahe_oracle.clahe(imgs[1][:, :, 0].copy(), 2.0, (8, 8)), block, params)
+    np.testing.assert_allclose(fm[0], ref_rgb, atol=2e-5 * np.abs(ref_rgb).max(), rtol=0)
+    np.testing.assert_allclose(fm[1], ref_grey, atol=2e-5 * np.abs(ref_grey).max(), rtol=0)
     m.close()
 
 

@@ -37,6 +37,10 @@ def test_emu_multi_layer_pipeline():
     ec.check_multi_layer_pipeline(HostDevice(), emu_library(), emu_scorer("fft"), hw=(40, 32), n_gallery=5, n_queries=2, batch=2)
 
 
+def test_emu_rgb_route():
+    ec.check_rgb_route(HostDevice(), emu_library())
+
+
 def test_emu_reference_surface():
     ec.check_reference_surface(HostDevice(), emu_library())
 

@@ -233,6 +233,12 @@ def test_multi_layer_pipeline(torch_dev, lib, fft_scorer):
     ec.check_multi_layer_pipeline(torch_dev, lib, fft_scorer, hw=(128, 96), taps=(16, 23, 30), n_gallery=9, n_queries=4, batch=4)
 
 
+def test_rgb_route(torch_dev, lib):
+    import extractor_cases as ec
+
+    ec.check_rgb_route(torch_dev, lib, hw=(96, 64), block=10)
+
+
 def test_extractor_reference_surface(torch_dev, lib):
     import extractor_cases as ec
 
