@@ -43,7 +43,7 @@ int64_t pair_tiles_per_launch(int pairs_per_tile, int threads) {
 size_t prepared_query_item_bytes(const NccGeom& g, int method) {
   size_t b;
   if (method == SPR_NCC_FFT)
-    b = sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan;
+    b = sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan + static_cast<size_t>(g.channels);  // + dead flags
   else
     b = sizeof(float) * static_cast<size_t>(g.channels) * g.th * g.tw;
   return align_up(b, 256);
@@ -52,7 +52,8 @@ size_t prepared_query_item_bytes(const NccGeom& g, int method) {
 size_t prepared_gallery_item_bytes(const NccGeom& g, int method) {
   size_t b;
   if (method == SPR_NCC_FFT)
-    b = static_cast<size_t>(g.channels) * (sizeof(cf) * g.spec_per_chan + sizeof(float) * g.inv_per_chan);
+    b = static_cast<size_t>(g.channels) * (sizeof(cf) * g.spec_per_chan + sizeof(float) * g.inv_per_chan) +
+        static_cast<size_t>(g.channels);  // + one dead flag per channel
   else
     b = sizeof(float) * static_cast<size_t>(g.channels) * g.ih * g.iw * 2;
   return align_up(b, 256);

@@ -84,9 +84,17 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   load_centred(maps, (item * g.channels + c) * static_cast<size_t>(raw_h) * raw_w, raw_w, g.crop, h, w, g.dtype, x0,
                red);
   float scale = 1.0f;
-  if (is_query) {
-    scale = template_scale(x0, h * w, red) * (1.0f / (static_cast<float>(C::NH) * static_cast<float>(C::NW)));
-  } else {
+  {
+    // dead flag of this (item, channel): a constant channel - all zero after ReLU, typically - has a zero centred map,
+    // hence a zero spectrum, and contributes exactly 0 to every pair (similarity.py:68-70); the six-wave pair kernel
+    // skips channels flagged on either side.  The flags follow the spectra (and the 1/sigma maps) of the item.
+    const float rs = template_scale(x0, h * w, red);  // 1 / sqrt(sum x0^2), 0 for an all-zero centred map
+    unsigned char* flags = item_base + static_cast<size_t>(g.channels) *
+                           (sizeof(cf) * C::kSpecPerChan + (is_query ? 0 : sizeof(float) * static_cast<size_t>(g.inv_per_chan)));
+    if (tid == 0) flags[c] = rs == 0.0f ? 1 : 0;
+    if (is_query) scale = rs * (1.0f / (static_cast<float>(C::NH) * static_cast<float>(C::NW)));
+  }
+  if (!is_query) {
     // 1/sigma map in the pair kernel's register order; slots no pixel maps to stay 0.
     float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
                  static_cast<size_t>(c) * g.inv_per_chan;

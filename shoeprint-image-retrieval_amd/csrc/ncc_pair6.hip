@@ -36,9 +36,6 @@ namespace {
 #ifndef SPR_ABL
 #define SPR_ABL 0
 #endif
-#ifndef SPR_P6_PIPE
-#define SPR_P6_PIPE 1
-#endif
 #ifdef SPR_STAMPS
 constexpr int kStampPoints = 12, kStampChannels = 8, kStampFirst = 8;
 __device__ unsigned long long g_stamps[12 * kStampChannels * kStampPoints];
@@ -57,6 +54,7 @@ struct Pair6Args {
   int tile0;    // first pair tile of this launch (launches are split so that the grid stays within HIP's limit)
   int tiles_g;  // pair tiles along the gallery
   int prio_mode;  // experiment: static wave priorities (SPR_P6_PRIO)
+  unsigned q_flags_off, g_flags_off;  // byte offset of the per-channel dead flags inside a prepared item
 };
 
 // 12-point transform as 3 x 4 (Good-Thomas): input n = (4 n1 + 3 n2) mod 12, output k = (4 k1 + 9 k2) mod 12,
@@ -105,8 +103,9 @@ struct Six {
   static constexpr int kRedOff = 2 * kHalfBytes;  // 2 x 8 floats of reduction scratch, then 2 barrier counters
   static constexpr int kTwOff = kRedOff + 128;
   static constexpr int kCtabOff = kTwOff + C::NH * 8;
-  static constexpr int kLdsBytes = kCtabOff + 48 * 4;
-  static_assert(kLdsBytes <= 160 * 1024, "one workgroup of two pairs per CU");
+  static constexpr int kListOff = kCtabOff + 48 * 4;  // two lists of live channels (uint16), sized at launch
+  static constexpr int kLdsBytes = kListOff;
+  static_assert(kLdsBytes + 2 * 2 * 1024 <= 160 * 1024, "one workgroup of two pairs per CU, up to 1024 channels");
   static_assert(kXbOff % 8 == 0 && kNyqOff % 8 == 0 && kHalfBytes % 16 == 0 && kTwOff % 8 == 0 && kCtabOff % 8 == 0, "");
 };
 
@@ -118,13 +117,13 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
              const float* __restrict__ ctab) {
   using S = Six<C>;
   constexpr int NT = S::NT, RS = S::RS, XR = S::XR;
-  constexpr int H2 = C::EH / 2;  // 16-byte loads per operand and column round
+  constexpr int H2 = C::EH / 2;  // 16-byte loads per operand and column unit
 
   // ---- which pairs ------------------------------------------------------------------------------
-  // A workgroup scores two queries against one gallery item (lanes [0, 384) the first, [384, 768) the second), in
-  // step: their gallery loads are the same lines at nearly the same time.  Workgroups are dealt round-robin over
-  // the 8 XCDs: workgroup w of a 16 x 16 tile (w % 8 = XCD) takes a 16-query x 2-gallery sub-tile, so a gallery
-  // item's 112 KB per channel has 16 readers on one L2.
+  // A workgroup scores two queries against one gallery item: lanes [0, 384) the first pair, [384, 768) the second, each
+  // at its own pace (the gallery item's lines are then in L2 for whichever pair comes second).  Workgroups are dealt
+  // round-robin over the 8 XCDs: workgroup w of a 16 x 16 tile (w % 8 = XCD) takes a 16-query x 2-gallery sub-tile,
+  // so a gallery item's 112 KB per channel has 16 readers on one L2.
   constexpr int kWgPerTile = kTileQ6 * kTileG6 / 2;
   const int tile = g.tile0 + static_cast<int>(blockIdx.x) / kWgPerTile;
   const int within = static_cast<int>(blockIdx.x) % kWgPerTile;
@@ -140,15 +139,20 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
   unsigned char* hl = lds + half * S::kHalfBytes;
   float* red = reinterpret_cast<float*>(lds + S::kRedOff) + half * 8;
   unsigned* bar = reinterpret_cast<unsigned*>(lds + S::kRedOff + 64) + half * 8;  // this pair's barrier counter
+  unsigned* nlive_p = bar + 2;                                                   // its number of live channels
   unsigned bar_target = 0;
   cf* R = reinterpret_cast<cf*>(hl + S::kImgOff);
-  cf* nyq = reinterpret_cast<cf*>(hl + S::kNyqOff);      // [channel & 1][0, NH): gallery column nw/2, [NH, 2NH): query's
+  cf* nyq = reinterpret_cast<cf*>(hl + S::kNyqOff);      // [buffer][0, NH): gallery column nw/2, [NH, 2NH): query's
   cf* twt_h = reinterpret_cast<cf*>(lds + S::kTwOff);    // w_NH^(+t p) at [p][t]
   cf* ctab2 = reinterpret_cast<cf*>(lds + S::kCtabOff);  // pre-twist cotangents, {c(a), c(a+1)} at [a/2][t]
+  unsigned short* chan = reinterpret_cast<unsigned short*>(lds + S::kListOff) + half * g.channels;
 
   const int tid0 = static_cast<int>(threadIdx.x) - half * NT;  // lane of the pair
   const int wv = uniform(tid0 >> 6);
   cf* xb = reinterpret_cast<cf*>(hl + S::kXbOff) + wv * S::kXbWave;
+
+  const unsigned char* g_item = pg + static_cast<size_t>(gi_item) * g_item_bytes;
+  const unsigned char* q_item = pq + static_cast<size_t>(qi) * q_item_bytes;
 
   if (tid0 == 0) *bar = 0u;
   if (half == 0) {
@@ -158,10 +162,26 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       ctab2[tid0] = cmake(ctab[(3 * a + 16 * t) % 48], ctab[(3 * (a + 1) + 16 * t) % 48]);
     }
   }
-
-  const unsigned char* g_item = pg + static_cast<size_t>(gi_item) * g_item_bytes;
-  const cf* qspec = reinterpret_cast<const cf*>(pq + static_cast<size_t>(qi) * q_item_bytes);
-  const int last_c = g.channels - 1;
+  // ---- live channels -------------------------------------------------------------------------------------------------
+  // A channel that is constant (all zero after ReLU, typically) in the query or in the gallery item contributes exactly
+  // 0 to every position (similarity.py:68-70: 0/0 -> NaN -> 0) while still counting in the divisor: the prep kernels
+  // flag such channels per item, and the pair walks the list of channels live on BOTH sides.
+  for (int k = tid0; k < g.channels; k += NT)
+    chan[k] = (q_item[g.q_flags_off + k] | g_item[g.g_flags_off + k]) ? 0xFFFFu : static_cast<unsigned short>(k);
+  __syncthreads();
+  if (tid0 == 0) {  // in-place compaction, in channel order (the write index never passes the read index)
+    int n = 0;
+    for (int k = 0; k < g.channels; ++k) {
+      const unsigned short v = chan[k];
+      if (v != 0xFFFFu) chan[n++] = v;
+    }
+    if (n == 0) chan[0] = 0;  // (nothing live: the loop below does not run; the prologue's loads still need an address)
+    *nlive_p = static_cast<unsigned>(n);
+  }
+  __syncthreads();
+  const int nlive = uniform(static_cast<int>(*nlive_p));
+  const int last_i = nlive > 0 ? nlive - 1 : 0;
+  auto chan_at = [&](int i) { return static_cast<int>(chan[i < last_i ? i : last_i]); };  // (prefetches past the end re-read)
 
   // ---- operand streams ---------------------------------------------------------------------------------
   // Buffer loads: descriptor = one prepared item, lane offset = 16 * lane of the pair, the rest (channel, column
@@ -169,13 +189,12 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
   float4 nxt[2 * H2];  // operands of the next column unit: H2 x (2 complex of G), H2 x (2 complex of Q)
   cf nyq_g, nyq_q;     // (every lane loads both sides' Nyquist value and keeps its own: a select between two resource
                        // descriptors would put the load into a waterfall loop)
-  const BufRsrc g_rs = make_rsrc(g_item, g_item_bytes), q_rs = make_rsrc(qspec, q_item_bytes);
+  const BufRsrc g_rs = make_rsrc(g_item, g_item_bytes), q_rs = make_rsrc(q_item, q_item_bytes);
   const unsigned voff16 = static_cast<unsigned>(tid0) * 16u;
   const unsigned voff_nyq = static_cast<unsigned>(tid0 % C::NH) * 8u + C::kNyqOffset * 8u;
   constexpr unsigned kChanBytes = C::kSpecPerChan * 8u;
   const unsigned inv_base = static_cast<unsigned>(g.channels) * kChanBytes;
   auto issue_unit = [&](int c, int rc) {  // column round rc of channel c: this wave's four columns
-    c = c > last_c ? last_c : c;          // the prefetches past the last channel re-read it (never used)
     const unsigned so = static_cast<unsigned>(c) * kChanBytes + static_cast<unsigned>(rc * H2 * NT * 16);
     if (SPR_ABL == 1) {
       for (int mm = 0; mm < 2 * H2; ++mm) nxt[mm] = make_float4(0.001f * so, 0.5f, 0.25f, 0.125f);
@@ -188,7 +207,6 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
     }
   };
   auto issue_nyq = [&](int c) {  // 2 NH = NT values: lanes [0, NH) keep the gallery's, [NH, 2 NH) the query's
-    c = c > last_c ? last_c : c;
     const unsigned so = static_cast<unsigned>(c) * kChanBytes;
     nyq_g = buf_ld8(g_rs, voff_nyq, so);
     nyq_q = buf_ld8(q_rs, voff_nyq, so);
@@ -200,12 +218,10 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
     // Static wave priorities.  The SIMD arbitrates by priority, then age, and the twelve waves sit three to a SIMD
     // in dispatch order: without this the first pair holds the four oldest waves and the second pair the four
     // youngest, and every workgroup ends with the first pair's SIMD slots idle while the second finishes.
-    // Raising waves 4, 5 and 8-11 gives each pair two waves of each rank (measured: +7 %).
-    const int gw = half * 6 + wv;  // wave of the workgroup, in dispatch (= age) order
-    int pr = 0;
-    if (g.prio_mode == 1) pr = gw >= 8 ? 1 : 0;
-    else if (g.prio_mode == 2) pr = (gw == 4 || gw == 5 || gw >= 8) ? 1 : 0;
-    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    // Raising waves 4, 5 and 8-11 gives each pair two waves of each rank (measured: +7 %; rotating the ranks per
+    // channel instead: -20 %).
+    const int gw = half * S::WAVES + wv;  // wave of the workgroup, in dispatch (= age) order
+    if (g.prio_mode == 2 && (gw == 4 || gw == 5 || gw >= 8)) __builtin_amdgcn_s_setprio(1);
   }
 #endif
   cf acc[6][2];
@@ -213,67 +229,51 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
   for (int pp = 0; pp < 6; ++pp) acc[pp][0] = acc[pp][1] = cmake(0.0f, 0.0f);
 
   // ---- prologue ---------------------------------------------------------------------------------------------------------
-  issue_nyq(0);
+  issue_nyq(chan_at(0));
   nyq[tid0] = tid0 < C::NH ? nyq_g : nyq_q;
-  issue_nyq(1);
+  issue_nyq(chan_at(1));
   nyq[NT + tid0] = tid0 < C::NH ? nyq_g : nyq_q;
-  issue_unit(0, 0);
+  issue_unit(chan_at(0), 0);
   __syncthreads();
-  cf za[12];  // unit A's product spectrum, formed one phase ahead
-#if SPR_P6_PIPE != 1
-  {
-    const int tid = tid0, lane = tid0 & 63, tc = lane & 15;
-    (void)lane;
-#pragma unroll
-    for (int mm = 0; mm < H2; ++mm) {
-      const float4 a = nxt[mm], b = nxt[H2 + mm];
-      za[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
-      za[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
-    }
-    if (tid < 16) {
-#pragma unroll
-      for (int m = 0; m < 12; ++m) za[m] = pk_add_i(za[m], cmul(nyq[tc + 16 * m], nyq[C::NH + tc + 16 * m]));
-    }
-    issue_unit(0, 1);
-  }
-#endif
 
-  // The column pass is software-pipelined so that a wave has vector work between issuing LDS reads and needing them:
+  // The channel loop, per wave (A, B = its unit - four image columns - of column round 0 / 1; the LDS reads of an
+  // exchange are issued before the arithmetic that follows them and consumed after it):
   //
-  //   12-point stage of A | B2(c-1) | product of B | exchange A | 12-point stage of B | exchange B | part 2 of A |
-  //   part 2 of B | B1(c) | row pass: image reads, pre-twist, 16-point stage, exchange | product of A(c+1) | 3-point stage
+  //   product + 12-point stage of A | B2 | product of B | exchange A | 12-point stage of B | 16-point stage + stores of A |
+  //   exchange B | 16-point stage + stores of B | B1 | row pass: image reads, pre-twist, 16-point stage, exchange,
+  //   3-point stage, * 1/sigma, accumulate
   //
-  // A, B = this wave's unit of column round 0 / 1.  The six waves of a pair meet twice per channel on a counter in LDS
-  // (group_barrier; the other pair of the workgroup runs at its own pace - s_barrier would march all twelve waves through
-  // the same phase at the same time):
-  //   B1(c)  every image column of channel c is stored - before the row pass reads the image;
-  //   B2(c)  every wave has finished reading the image of channel c - before the first LDS store of channel c+1; it
-  //          sits behind part 1 of A (registers only), so a wave that leaves the row pass early has work before it waits.
-  // Channel c+2's Nyquist values are loaded during channel c and stored to LDS at its end, i.e. before B2(c); the wave
-  // with image column 0 reads them in part 1 of A(c+2), after B1(c+1): two buffers.
-  for (int c = 0; c < g.channels; ++c) {
+  // The six waves of a pair meet twice per channel on a counter in LDS (group_barrier); the other pair of the workgroup
+  // runs at its own pace - s_barrier would march all twelve waves through the same phase at the same time, each pipe busy
+  // in bursts and idle in between (measured: 254 k pairs/s with s_barrier, 260 k with the pair barriers, before the rest):
+  //   B1  every image column of this channel is stored - before the row pass reads the image;
+  //   B2  every wave has finished reading the image of the previous channel - before the first LDS store of this one; it
+  //       sits behind part 1 of A (registers only), so a wave that leaves the row pass early has work before it waits.
+  // The Nyquist values of the live channel after next are loaded during this channel and stored to LDS at its end, i.e.
+  // before the next B2; wave 0 reads them in its part 1 two channels on: two buffers.
+  for (int ci = 0; ci < nlive; ++ci) {
+    const int c = chan_at(ci), c1 = chan_at(ci + 1), c2 = chan_at(ci + 2);  // this live channel and the next two
 #ifdef SPR_STAMPS
     unsigned long long st[kStampPoints] = {};
 #endif
     SPR_STAMP(0);
-      // lane coordinates, re-derived from an opaque copy of the lane id every channel: otherwise the ~20 lane addresses
-      // and constants below are hoisted out of the channel loop and sit in registers through every phase (spr::opaque)
-      const int tid = opaque(tid0);
-      const int lane = tid & 63;
+    // lane coordinates, re-derived from an opaque copy of the lane id every channel: otherwise the ~20 lane addresses
+    // and constants below are hoisted out of the channel loop and sit in registers through every phase (spr::opaque)
+    const int tid = opaque(tid0);
+    const int lane = tid & 63;
     const int g4 = lane >> 4, tc = lane & 15;  // column role: group of the wave, lane of the group
 
-    // ---- pieces of the column pass (a UNIT = this wave's four columns of one column round) ---------------------------
     // part 1, registers only: operands -> product spectrum (two operand registers become one) ...
-    auto product = [&](cf (&z)[12], int c, int rc) {
-  #pragma unroll
+    auto product = [&](cf (&z)[12], int rc) {
+#pragma unroll
       for (int mm = 0; mm < H2; ++mm) {
         const float4 a = nxt[mm], b = nxt[H2 + mm];
         z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
         z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
       }
       if (rc == 0 && tid < 16) {  // image column 0: pack column nw/2 into its imaginary part
-        const cf* nq = nyq + (c & 1) * NT;
-  #pragma unroll
+        const cf* nq = nyq + (ci & 1) * NT;
+#pragma unroll
         for (int m = 0; m < 12; ++m) {
           const int k1 = tc + 16 * m;
           z[m] = pk_add_i(z[m], cmul(nq[k1], nq[C::NH + k1]));
@@ -283,7 +283,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
     // ... -> 12-point stage -> twiddles
     auto stage12 = [&](cf (&z)[12]) {
       pfa12<+1>(z);
-  #pragma unroll
+#pragma unroll
       for (int p = 1; p < 12; ++p) z[p] = cmul(z[p], twt_h[p * 16 + tc]);
     };
     // exchange: row p of the wave's image holds U[p] of all 64 lanes.  Rows 0..5 in the wave's buffer, rows 6..11 in the
@@ -297,14 +297,16 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       wave_sync();  // every lane has read the previous unit's rows
       cf* w0 = xb + lane;
       cf* w1 = own + lane;
-  #pragma unroll
-      for (int p = 0; p < 6; ++p) w0[p * XR] = z[p];
-  #pragma unroll
-      for (int p = 6; p < 12; ++p) w1[(p - 6) * XR] = z[p];
+      if (SPR_ABL != 3) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) w0[p * XR] = z[p];
+#pragma unroll
+        for (int p = 6; p < 12; ++p) w1[(p - 6) * XR] = z[p];
+      }
       wave_sync();
       // lane tc < 12 owns sub-transform p = tc; the four idle lanes of a group re-read row 0 (finite values)
       const cf* rd = (tc < 6 ? xb + tc * XR : (tc < 12 ? own + (tc - 6) * XR : xb)) + 16 * g4;
-  #pragma unroll
+#pragma unroll
       for (int tt = 0; tt < 16; ++tt) y[tt] = rd[tt];
     };
     // part 2: 16-point stage of the owned sub-transform, rows tc + 12 s of image slot rc * 24 + 4 wv + g4
@@ -312,53 +314,45 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
     auto part2 = [&](cf (&y)[16], int rc) {
       wave_sync();  // (every lane has its row before the image stores below overwrite rows 6..11 of the exchange)
       if (tc < 12) {
-        Dft<16, +1>::run(y);
+        if (SPR_ABL != 4) Dft<16, +1>::run(y);
         cf* col = R + (rc * 24 + 4 * wv + g4) * RS + tc;
-  #pragma unroll
-        for (int s = 0; s < 11; ++s) col[12 * s] = y[s];
+        if (SPR_ABL != 3) {
+#pragma unroll
+          for (int s = 0; s < 11; ++s) col[12 * s] = y[s];
+        }
       }
     };
 
     // =================================== column pass ===================================
     {
-      cf ya[16], zb[12], yb[16];
-      issue_nyq(c + 2);
-#if SPR_P6_PIPE == 1
-      product(za, c, 0);
-      issue_unit(c, 1);
-#endif
-      stage12(za);  // (pipe 2: unit A's product was formed at the end of the previous row pass / in the prologue)
+      cf za[12], ya[16], zb[12], yb[16];
+      issue_nyq(c2);
+      product(za, 0);
+      issue_unit(c, 1);  // unit B's operands fly during the 12-point stage of A and the wait
+      stage12(za);
 #pragma unroll
       for (int p = 0; p < 12; ++p) pin(za[p]);  // (or the compiler sinks the arithmetic below the wait)
       SPR_STAMP(1);
       bar_target += S::WAVES;
-      if (SPR_ABL != 2) group_barrier(bar, bar_target);  // B2(c-1)
+      if (SPR_ABL != 2) group_barrier(bar, bar_target);  // B2
       SPR_STAMP(2);
-      product(zb, c, 1);  // before A's exchange: its 16 reads then overlap 24 live registers, not 48
+      product(zb, 1);  // before A's exchange: its 16 reads then overlap 24 live registers, not 48
       sched_fence();
       exchange(za, ya, 0);
       sched_fence();
-      stage12(zb);        // hides exchange A
+      stage12(zb);  // hides exchange A
       sched_fence();
+      issue_unit(c1, 0);  // consumed after the row pass
       SPR_STAMP(3);
-#if SPR_P6_PIPE == 1
-      issue_unit(c + 1, 0);
       part2(ya, 0);
-      exchange(zb, yb, 1);
-      part2(yb, 1);
-#else
-      exchange(zb, yb, 1);
-      sched_fence();
-      part2(ya, 0);       // hides exchange B
-      sched_fence();
       SPR_STAMP(4);
-      issue_unit(c + 1, 0);  // consumed in the row pass
+      exchange(zb, yb, 1);
+      SPR_STAMP(5);
       part2(yb, 1);
-#endif
       SPR_STAMP(6);
     }
     bar_target += S::WAVES;
-    if (SPR_ABL != 2) group_barrier(bar, bar_target);  // B1(c)
+    if (SPR_ABL != 2) group_barrier(bar, bar_target);  // B1
     SPR_STAMP(7);
     // =================================== row pass ===================================
     {
@@ -368,7 +362,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       // pass, so surplus groups transform real - finite - rows of the circular correlation; their 1/sigma is 0.)
       const int grp_r = grp < C::kRowGroups ? grp : C::kRowGroups - 1;
       const int row = wv * C::kRowGroups + grp_r;  // a wave reads ONLY its own 21 rows (it reuses them below)
-      const int tm = t3 == 0 ? 0 : 3 - t3;    // lane of the mirrored column 48 - k
+      const int tm = t3 == 0 ? 0 : 3 - t3;         // lane of the mirrored column 48 - k
       const cf* dbase = R + t3 * RS + row;
       const cf* mbase = R + tm * RS + row;
       const cf* cc = ctab2 + t3;
@@ -380,8 +374,8 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
         for (int h = 0; h < 2; ++h) {
           const int a = 2 * a2 + h;
           const int ra = (3 * a) % 16, rm = (3 * ((16 - a) % 16)) % 16;
-          const cf av = SPR_ABL == 5 ? cmake(0.5f * a, ck.x) : dbase[3 * ra * RS];
-          const cf bv = SPR_ABL == 5 ? cmake(ck.y, 0.25f * a) : mbase[3 * rm * RS];
+          const cf av = dbase[3 * ra * RS];
+          const cf bv = mbase[3 * rm * RS];
           cf v = h == 0 ? pk_conj_iaxpy<0>(av, ck, bv) : pk_conj_iaxpy<1>(av, ck, bv);
           if (a == 0) {  // k = 0 (lane 0 of the group): image slot 0 holds (Y[0], Y[nw/2]), both real
             const cf v0 = cmake(av.x + av.y, av.x - av.y);
@@ -398,7 +392,8 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       float4 iv[6];
       const unsigned so_inv = inv_base + static_cast<unsigned>(c) * static_cast<unsigned>(g.inv_per_chan) * 4u;
 #pragma unroll
-      for (int pp = 0; pp < 6; ++pp) iv[pp] = SPR_ABL == 1 ? make_float4(1.f, 1.f, 1.f, 1.f) : buf_ld16(g_rs, voff16, so_inv + pp * NT * 16);
+      for (int pp = 0; pp < 6; ++pp)
+        iv[pp] = SPR_ABL == 1 ? make_float4(1.f, 1.f, 1.f, 1.f) : buf_ld16(g_rs, voff16, so_inv + pp * NT * 16);
       // 3-point lane stage.  The exchange image (16 rows of 64 lanes) lies in the image rows this wave has just
       // consumed - rows 21 wv .. 21 wv + 20 of all 48 slots, which no other wave reads: exchange row r takes slots
       // 3r .. 3r+2 (21 lanes each, a row group never straddles two) - so all 16 values leave in one burst and
@@ -421,12 +416,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)  // row n1 = t3 + 3 pp; rows 16, 17 do not exist: those lanes re-read row 15
-          yv[pp][tt] = SPR_ABL == 5 ? z[(3 * pp + tt) % 16] : (pp < 5 ? rx[9 * pp * RS + tt] : rx15[tt]);
-      sched_fence();
-#if SPR_P6_PIPE != 1
-      product(za, c + 1, 0);  // the next channel's unit A (operands requested during the column pass): hides the reads
-      sched_fence();
-#endif
+          yv[pp][tt] = pp < 5 ? rx[9 * pp * RS + tt] : rx15[tt];
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) {
         const cf y0 = yv[pp][0], y1 = yv[pp][1], y2 = yv[pp][2];
@@ -450,16 +440,13 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
           }
         }
       }
-#if SPR_P6_PIPE != 1
-      issue_unit(c + 1, 1);  // unit B of the next channel: consumed behind B2
-#endif
-      nyq[(c & 1) * NT + tid] = tid < C::NH ? nyq_g : nyq_q;  // channel c + 2's
+      nyq[(ci & 1) * NT + tid] = tid < C::NH ? nyq_g : nyq_q;  // the live channel after next's
     }
     SPR_STAMP(10);
 #ifdef SPR_STAMPS
-    if (blockIdx.x == 777 && (tid0 & 63) == 0 && c >= kStampFirst && c < kStampFirst + kStampChannels) {
+    if (blockIdx.x == 777 && (tid0 & 63) == 0 && ci >= kStampFirst && ci < kStampFirst + kStampChannels) {
       for (int i = 0; i < kStampPoints; ++i)
-        g_stamps[((half * 6 + wv) * kStampChannels + (c - kStampFirst)) * kStampPoints + i] = st[i];
+        g_stamps[((half * 6 + wv) * kStampChannels + (ci - kStampFirst)) * kStampPoints + i] = st[i];
     }
 #endif
   }
@@ -508,6 +495,10 @@ int launch_pair6(const NccGeom& g, const void* pq, int64_t nq, const void* pg, i
   a.channels = g.channels; a.nq = static_cast<int>(nq); a.ng = static_cast<int>(ng);
   a.ih = g.ih; a.iw = g.iw; a.inv_per_chan = g.inv_per_chan; a.accumulate = accumulate;
   a.tiles_g = ceil_div(static_cast<int>(ng), kTileG6);
+  a.q_flags_off = static_cast<unsigned>(sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan);
+  a.g_flags_off = static_cast<unsigned>(static_cast<size_t>(g.channels) * (sizeof(cf) * g.spec_per_chan + sizeof(float) * g.inv_per_chan));
+  if (g.channels > 1024) { set_error("pair6_kernel: at most 1024 channels"); return SPR_ERR_UNSUPPORTED; }
+  const size_t lds_bytes = S::kLdsBytes + 2 * sizeof(unsigned short) * static_cast<size_t>(g.channels);
   { const char* v = std::getenv("SPR_P6_PRIO"); a.prio_mode = v && *v ? std::atoi(v) : 2; }
   const int64_t tiles = static_cast<int64_t>(ceil_div(static_cast<int>(nq), kTileQ6)) * a.tiles_g;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair6_kernel<C6>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -518,7 +509,7 @@ int launch_pair6(const NccGeom& g, const void* pq, int64_t nq, const void* pg, i
     const int64_t n = tiles - t0 < max_tiles ? tiles - t0 : max_tiles;
     a.tile0 = static_cast<int>(t0);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(pair6_kernel<C6>), dim3(static_cast<unsigned>(n * (kTileQ6 * kTileG6 / 2))), dim3(2 * C6::NT),
-                       S::kLdsBytes, stream, a, static_cast<const unsigned char*>(pq),
+                       lds_bytes, stream, a, static_cast<const unsigned char*>(pq),
                        prepared_query_item_bytes(g, SPR_NCC_FFT), static_cast<const unsigned char*>(pg),
                        prepared_gallery_item_bytes(g, SPR_NCC_FFT), scores, static_cast<long long>(ld),
                        static_cast<long long>(col0), maps_out, tw_h, ctab);

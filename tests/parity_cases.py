@@ -183,6 +183,26 @@ def check_big_mode(make_scorer, monkeypatch, full):
     np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
 
 
+def check_sparse_channels(scorer, c=5):
+    """Post-ReLU maps of real prints have channels that are entirely zero (or constant) in one image: they contribute
+    exactly 0 and still count in the divisor (similarity.py:68-70, 96, 108).  The prep kernels flag them and the six-wave
+    pair kernel walks only the channels live on both sides: dead patterns that differ between the two queries of a
+    workgroup and between gallery items, a constant non-zero channel, and a pair with NO live channel (score 0)."""
+    qh, qw = 128, 64
+    q = [synth.gallery_features(95, 100 + i, c, qh, qw) for i in range(3)]
+    g = [synth.gallery_features(95, i, c, qh, qw) for i in range(3)]
+    q[0][[0, c - 2]] = 0
+    q[1][1] = 0.75      # constant, non-zero: zero after centring
+    g[0][[1, min(2, c - 1)]] = 0
+    g[1][:] = 0         # no live channel against anybody
+    g[2][c - 1] = 0
+    q[2][:c - 1] = 0    # live only in the channel g[2] lacks: nothing in common with g[2]
+    mat = scorer.score_matrix(q, g)
+    ref = oracle.similarity_matrix(q, g, precise=True)
+    np.testing.assert_allclose(mat, ref, atol=TIGHT, rtol=0)
+    assert np.all(mat[:, 1] == 0.0) and mat[2, 2] == 0.0
+
+
 def check_launch_slicing(make_scorer, monkeypatch, big_c=2):
     """HIP refuses grids of 2^32 work-items and more, so the pair launches are cut into slices of pair tiles
     (gallery items for the direct kernel).  With the slice size forced down to ONE tile (SPR_NCC_MAX_TILES=1) a

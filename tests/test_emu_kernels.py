@@ -56,6 +56,10 @@ def test_emu_big_mode(monkeypatch):
     pc.check_big_mode(lambda: emu_scorer("fft"), monkeypatch, full=False)
 
 
+def test_emu_sparse_channels():
+    pc.check_sparse_channels(emu_scorer("fft"), c=3)
+
+
 def test_emu_launch_slicing(monkeypatch):
     pc.check_launch_slicing(lambda m: emu_scorer(m), monkeypatch, big_c=1)
 

@@ -85,6 +85,10 @@ def test_config_selects_the_scorer(lib):
     pc.check_config_selects_the_scorer(lambda cfg: scorer_from_config(cfg, library=lib))
 
 
+def test_sparse_channels(fft_scorer):
+    pc.check_sparse_channels(fft_scorer, c=7)
+
+
 def test_launch_slicing(lib, monkeypatch):
     from shoeprint_image_retrieval_amd.similarity import NccScorer
 

@@ -25,8 +25,9 @@ fn = lib.cdll.spr_debug_read_stamps; fn.argtypes = [ctypes.c_void_p, ctypes.c_in
 assert fn(buf, len(buf)) == 0
 st = np.array(buf, dtype=np.int64).reshape(12, CH, P)
 d = np.diff(st, axis=2)  # [wave, channel, phase]
-names = ["c0: operands->product", "c0: dft12+twiddle", "barrier 2 (prev. channel)", "c0: xwrite", "c0: xread+dft16+store",
-         "c1: product", "c1: rest", "barrier 1", "row: reads+pretwist", "row: dft16+xwrite", "row: xread+dft3+acc"]
+names = ["A: product + 12-point stage", "B2 wait", "product B, exchange A, 12-point stage B", "16-point stage + stores A",
+         "exchange B", "16-point stage + stores B", "B1 wait", "row: image reads + pre-twist", "row: 16-point stage + exchange writes",
+         "row: exchange reads, 3-point stage, accumulate"]
 print("cycles per channel (mean over 8 channels), per wave; total =", (st[:, 1:, 0] - st[:, :-1, 0]).mean())
 for i, n in enumerate(names):
     print(f"{n:28s} mean {d[:, :, i].mean():8.0f}   per wave: " + " ".join(f"{v:6.0f}" for v in d[:, :, i].mean(axis=1)))
