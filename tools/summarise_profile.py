@@ -69,14 +69,20 @@ def main():
                [{k: e[k] for k in ("kernel", "calls", "avg_ms", "total_ms", "pct")} for e in stats],
                "FETCH_SIZE (KiB, summed over dispatches; own rocprofv3 --pmc pass, bench.py --steps 1 --warmup 0)": fetch,
                "WRITE_SIZE (KiB, summed over dispatches; own rocprofv3 --pmc pass, bench.py --steps 1 --warmup 0)": write}
-    if "pair_fft_kernel" in fetch and "pair_fft_kernel" in write:
-        f = fetch["pair_fft_kernel"]; w = write["pair_fft_kernel"]
+    pair = next((k for k in ("pair6_kernel", "pair_fft_kernel") if k in fetch and k in write), None)
+    if pair:
+        import hashlib
+        f = fetch[pair]; w = write[pair]
         fb = f["sum_kib"] * 1024 / f["dispatches"]; wb = w["sum_kib"] * 1024 / w["dispatches"]
-        summary["pair_fft_kernel traffic per launch"] = {
+        lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shoeprint-image-retrieval_amd",
+                           "libshoeprint_mi355x.so")
+        summary["pair kernel traffic per launch"] = {
+            "kernel": pair, "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
             "FETCH_SIZE_bytes_raw": fb, "FETCH_SIZE_bytes_x2_gfx950_correction": 2 * fb, "WRITE_SIZE_bytes": wb,
             "hbm_bytes_per_launch": 2 * fb + wb, "hbm_bytes_per_pair": (2 * fb + wb) / pairs, "pairs_per_launch": pairs,
             "note": "FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): "
-                    "doubled. Counters are memory-side L2 requests and include Infinity-Cache hits."}
+                    "doubled. Counters are memory-side L2 requests and include Infinity-Cache hits.  bench.py reports this figure "
+                    "as roofline.traffic only while lib_sha16 matches the library it runs (the counters cannot be read in-run)."}
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     json.dump(summary, open(os.path.join(root, f"{tag}_rocprof_summary.json"), "w"), indent=1)
     with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
@@ -84,7 +90,7 @@ def main():
         for e in stats:
             for v in e["variants"]:
                 wr.writerow([v["name"], v["calls"], round(v["avg_ms"], 4)])
-    print(json.dumps(summary.get("pair_fft_kernel traffic per launch", {}), indent=1))
+    print(json.dumps(summary.get("pair kernel traffic per launch", {}), indent=1))
     for e in stats[:6]:
         print(e["kernel"], e["calls"], e["avg_ms"], e["pct"])
 
