@@ -53,11 +53,13 @@ SIGNAL, NOISE, MAX_SHIFT = 1, 126, 3  # the hardest queries the exact integer ge
 # true-match score ~0.006 against ~0.004 for the runner-up at conv3_3 size (tools/ubench/noise_sweep.py)
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_BF16_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA (the 2:1-sparsity figure is twice this)
 
 LAYERS = {"conv3_3": (256, 128, 64), "conv4_3": (512, 64, 32), "conv5_3": (512, 32, 16), "resnet50_layer3": (1024, 32, 16)}
 WORKLOADS = {
     2: dict(name="WVU2019-shaped VGG16 conv3_3 NCC", layers=["conv3_3"], storage="float32", q=100, g=1500),
-    3: dict(name="ResNet50-layer3-shaped NCC (extractor bypassed)", layers=["resnet50_layer3"], storage="bfloat16", q=64, g=10000),
+    3: dict(name="ResNet50-layer3-shaped NCC (extractor bypassed)", layers=["resnet50_layer3"], storage="bfloat16", q=64, g=10000,
+            noise=60),  # 28 x 12 cropped maps carry 1/18 of the pixels of conv3_3: the hardest setting drowns the match
     4: dict(name="100k-gallery VGG16 conv3_3 NCC, chunked prepared gallery", layers=["conv3_3"], storage="float16", q=64, g=12500),
     5: dict(name="multi-layer (conv3_3 + conv4_3 + conv5_3) fused NCC", layers=["conv3_3", "conv4_3", "conv5_3"],
             storage="float16", q=64, g=12500),
@@ -267,12 +269,15 @@ def main(argv=None):
     ap.add_argument("--method", default="auto", choices=["auto", "fft", "direct"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-sample", action="store_true", help="(kept for old command lines: the parity check rides on the CPU leg)")
+    ap.add_argument("--noise", type=int, default=None, help="noise amplitude of the synthetic queries (default: the workload's)")
     ap.add_argument("--no-extractor", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--cpu-sample-queries", type=int, default=0)
     ap.add_argument("--cpu-sample-gallery", type=int, default=0)
     ap.add_argument("--emu", action="store_true", help="tests: CPU emulation of the kernels, tiny workload, gloo")
     args = ap.parse_args(argv)
+    global NOISE
+    NOISE = args.noise if args.noise is not None else WORKLOADS[args.config].get("noise", NOISE)
 
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(argv, args.gpus)
@@ -432,7 +437,31 @@ def main(argv=None):
         pair_ms = sum(a.elapsed_time(b) for a, b, _ in pair_events)
         pair_pairs = sum(p for _, _, p in pair_events)
         launches = len(pair_events)
-        if args.config == 3:
+        if plan0.method == 4:
+            # matrix-core direct form (ncc_mfma.hip): priced against the dense bf16 MFMA peak on the ALGORITHMIC flops of the
+            # sliding-window form, 2 * taps * positions per pair and channel; the kernel issues 2.67x that (template rows padded
+            # 12 -> 16 taps, the centred search map entering as hi + lo), which the fraction below therefore counts as loss
+            taps = ih * iw
+            flops_pair = 2.0 * taps * taps * c0
+            achieved = flops_pair * pair_pairs / (pair_ms * 1e-3) / 1e12
+            issued = 2.0 * (ih * 16) * taps * 2 * c0
+            bytes_pair = c0 * h0 * w0 * 2
+            hbm = bytes_pair * pair_pairs / (pair_ms * 1e-3) / 1e9
+            roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pair_mfma_kernel",
+                        "launches": launches, "avg_launch_ms": round(pair_ms / launches, 3),
+                        "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 4),
+                        "issued_mfma_gflop_per_pair": round(issued / 1e9, 4),
+                        "issued_frac_of_peak": round(issued * pair_pairs / (pair_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        "kernel_time_share": round(pair_ms * 1e-3 / dt, 3),
+                        "hbm": {"algorithmic_bytes_per_pair": bytes_pair, "achieved_gbs": round(hbm, 1), "peak_gbs": PEAK_HBM_GBS,
+                                "frac": round(hbm / PEAK_HBM_GBS, 4),
+                                "note": "SURVEY 8d prices an UNBATCHED pair at one bf16 gallery tensor; 64 queries share every "
+                                        "gallery read here, so HBM is not what bounds this kernel"},
+                        "note": "v_mfma_f32_16x16x32_bf16, exact bf16 products, f32 accumulation; peak = dense bf16 2.5 PFLOP/s"}
+            if observed:
+                roofline["observed"] = dict(observed, nominal_sclk_mhz=2400)
+        elif args.config == 3:
             # small maps: the kernel streams prepared spectra from L2 / HBM; SURVEY §8d prices it against HBM with the
             # compulsory bytes of an unbatched pair = one gallery feature tensor (bf16: 1.05 MB)
             bytes_pair = c0 * h0 * w0 * 2
@@ -483,10 +512,10 @@ def main(argv=None):
         "metric": "query x gallery NCC pairs/sec", "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if plan0.method == 4 else "f32", "data": "synthetic",
         "config": {"workload": f"config {args.config}: {wl['name']}: Q={nq} x G={ng_total} ({ng_local}/GPU), features {shapes} "
                                f"stored as {storage}, rotations/scales none, queries signal {SIGNAL} / noise {NOISE}",
-                   "method": {1: "fft", 2: "direct"}[plan0.method], "fft_grid": list(plan0.fft_size),
+                   "method": {1: "fft", 2: "direct", 4: "mfma"}[plan0.method], "fft_grid": list(plan0.fft_size),
                    "gallery_chunk": chunks[0], "gallery_chunks_per_step": math.ceil(ng_local / chunks[0]),
                    "storage": storage, "parallelism": f"gallery-shard x{world}",
                    "streams": len(streams) if streams else 1},

@@ -54,13 +54,17 @@ enum spr_dtype { SPR_F32 = 0, SPR_F16 = 1, SPR_BF16 = 2 };
 
 /* Which pair kernel scores a (query, gallery) pair. */
 enum spr_ncc_method {
-  SPR_NCC_AUTO = 0,   /* FFT when an instantiated grid covers the padded maps, else direct */
+  SPR_NCC_AUTO = 0,   /* bf16 matrix cores when SPR_NCC_MFMA covers the plan, else FFT when an instantiated grid covers the
+                         padded maps, else direct */
   SPR_NCC_FFT = 1,    /* frequency-domain correlation, inverse 2-D FFT per channel: LDS-resident for maps up to
                          ~12 k cropped pixels, working set in a plan-owned device workspace beyond that (maps
                          up to 256 x 128 on the 384 x 192 grid); the plan allocates the workspace itself and
                          spr_ncc_plan_create returns SPR_ERR_WORKSPACE if that allocation fails */
   SPR_NCC_DIRECT = 2, /* sliding-window correlation in LDS (any shape that fits LDS) */
-  SPR_NCC_FFT_POW2 = 3 /* as SPR_NCC_FFT but restricted to power-of-two grids (A/B and fallback for the 3*2^k grids) */
+  SPR_NCC_FFT_POW2 = 3, /* as SPR_NCC_FFT but restricted to power-of-two grids (A/B and fallback for the 3*2^k grids) */
+  SPR_NCC_MFMA = 4    /* sliding-window correlation as a [queries x taps] x [taps x positions] product on the bf16 matrix
+                         cores: bfloat16 storage, cropped maps of 28 x 12 on both sides (ResNet50 layer3 / VGG16 conv5_3
+                         of a 512 x 256 image, crop 2); SPR_ERR_UNSUPPORTED for anything else */
 };
 
 typedef void* spr_stream_t;
@@ -88,7 +92,7 @@ typedef struct spr_ncc_shape {
 
 int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** plan_out);
 void spr_ncc_plan_destroy(spr_ncc_plan* plan);
-/* The method the plan resolved SPR_NCC_AUTO to (SPR_NCC_FFT / SPR_NCC_DIRECT). */
+/* The method the plan resolved SPR_NCC_AUTO to (SPR_NCC_FFT / SPR_NCC_DIRECT / SPR_NCC_MFMA). */
 int spr_ncc_plan_method(const spr_ncc_plan* plan);
 /* FFT grid the plan uses ({0,0} for the direct method): rows, cols. */
 int spr_ncc_plan_fft_size(const spr_ncc_plan* plan, int32_t* rows, int32_t* cols);

@@ -15,8 +15,8 @@ DEFAULT_PATH = os.path.join(_HERE, "libshoeprint_mi355x.so")
 
 SPR_OK = 0
 F32, F16, BF16 = 0, 1, 2
-NCC_AUTO, NCC_FFT, NCC_DIRECT, NCC_FFT_POW2 = 0, 1, 2, 3
-METHOD_NAMES = {NCC_AUTO: "auto", NCC_FFT: "fft", NCC_DIRECT: "direct", NCC_FFT_POW2: "fft_pow2"}
+NCC_AUTO, NCC_FFT, NCC_DIRECT, NCC_FFT_POW2, NCC_MFMA = 0, 1, 2, 3, 4
+METHOD_NAMES = {NCC_AUTO: "auto", NCC_FFT: "fft", NCC_DIRECT: "direct", NCC_FFT_POW2: "fft_pow2", NCC_MFMA: "mfma"}
 
 
 class NccShape(C.Structure):

@@ -42,6 +42,7 @@ int64_t pair_tiles_per_launch(int pairs_per_tile, int threads) {
 
 size_t prepared_query_item_bytes(const NccGeom& g, int method) {
   size_t b;
+  if (method == SPR_NCC_MFMA) return mfma_query_item_bytes(g);
   if (method == SPR_NCC_FFT)
     b = sizeof(cf) * static_cast<size_t>(g.channels) * g.spec_per_chan + static_cast<size_t>(g.channels);  // + dead flags
   else
@@ -51,6 +52,7 @@ size_t prepared_query_item_bytes(const NccGeom& g, int method) {
 
 size_t prepared_gallery_item_bytes(const NccGeom& g, int method) {
   size_t b;
+  if (method == SPR_NCC_MFMA) return mfma_gallery_item_bytes(g);
   if (method == SPR_NCC_FFT)
     b = static_cast<size_t>(g.channels) * (sizeof(cf) * g.spec_per_chan + sizeof(float) * g.inv_per_chan) +
         static_cast<size_t>(g.channels);  // + one dead flag per channel
@@ -63,7 +65,7 @@ size_t prepared_gallery_item_bytes(const NccGeom& g, int method) {
 
 struct spr_ncc_plan {
   spr::NccGeom geom;
-  int method;              // resolved: SPR_NCC_FFT or SPR_NCC_DIRECT
+  int method;              // resolved: SPR_NCC_FFT, SPR_NCC_DIRECT or SPR_NCC_MFMA
   spr::cf* tw_h = nullptr;  // device: exp(-2*pi*i*k/nh), k < nh
   spr::cf* tw_w = nullptr;  // device: exp(-2*pi*i*k/nw), k < nw
   unsigned* team_sync = nullptr;  // device: arrival counters of the pair kernel's 8 workgroup teams
@@ -112,7 +114,7 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
     return SPR_ERR_ARG;
   }
   if (shape->method != SPR_NCC_AUTO && shape->method != SPR_NCC_FFT && shape->method != SPR_NCC_DIRECT &&
-      shape->method != SPR_NCC_FFT_POW2) {
+      shape->method != SPR_NCC_FFT_POW2 && shape->method != SPR_NCC_MFMA) {
     set_error("spr_ncc_plan_create: unknown method %d", shape->method);
     return SPR_ERR_ARG;
   }
@@ -130,7 +132,15 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   int method = 0;
   NccGeom gf = g, gd = g;
   const bool fft_ok = fft_geometry(gf, shape->method == SPR_NCC_FFT_POW2), direct_ok = direct_geometry(gd);
-  if (shape->method == SPR_NCC_FFT || shape->method == SPR_NCC_FFT_POW2) {
+  // SPR_NCC_MFMA=0 in the environment keeps SPR_NCC_AUTO off the matrix-core kernel (A/B runs)
+  const char* mfma_env = std::getenv("SPR_NCC_MFMA");
+  const bool mfma_ok = mfma_geometry(g), mfma_auto = mfma_ok && !(mfma_env && mfma_env[0] == '0');
+  if (shape->method == SPR_NCC_MFMA) {
+    if (!mfma_ok) { set_error("matrix-core method: bfloat16 maps of 28x12 (cropped) on both sides only, got dtype %d, query %dx%d vs gallery %dx%d", g.dtype, g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
+    method = SPR_NCC_MFMA;
+  } else if (shape->method == SPR_NCC_AUTO && mfma_auto) {
+    method = SPR_NCC_MFMA;
+  } else if (shape->method == SPR_NCC_FFT || shape->method == SPR_NCC_FFT_POW2) {
     if (!fft_ok) { set_error("FFT method: no instantiated LDS-resident grid fits query %dx%d vs gallery %dx%d", g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
     method = SPR_NCC_FFT;
   } else if (shape->method == SPR_NCC_DIRECT) {
@@ -147,7 +157,7 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   spr_ncc_plan* p = new (std::nothrow) spr_ncc_plan();
   if (!p) { set_error("out of host memory"); return SPR_ERR_ARG; }
   p->method = method;
-  p->geom = method == SPR_NCC_FFT ? gf : gd;
+  p->geom = method == SPR_NCC_FFT ? gf : method == SPR_NCC_MFMA ? g : gd;
   if (method == SPR_NCC_FFT) {
     int rc = make_twiddles(p->geom.nh, &p->tw_h);
     if (rc == SPR_OK) rc = make_twiddles(p->geom.nw, &p->tw_w);
@@ -222,6 +232,7 @@ static int prepare(spr_ncc_plan* plan, bool is_query, const void* maps, int64_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan->method == SPR_NCC_FFT)
     return launch_prep_fft(plan->geom, is_query, maps, n, prepared, plan->tw_h, plan->tw_w, plan->ws, s);
+  if (plan->method == SPR_NCC_MFMA) return launch_prep_mfma(plan->geom, is_query, maps, n, prepared, s);
   return launch_prep_direct(plan->geom, is_query, maps, n, prepared, s);
 }
 
@@ -245,6 +256,8 @@ extern "C" int spr_ncc_score(spr_ncc_plan* plan, const void* pq, int64_t nq, con
   if (plan->method == SPR_NCC_FFT)
     return launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
                            plan->tw_w, plan->team_sync, plan->ws, s);
+  if (plan->method == SPR_NCC_MFMA)
+    return launch_pair_mfma(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
   return launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
 }
 
@@ -254,5 +267,6 @@ extern "C" int spr_ncc_maps(spr_ncc_plan* plan, const void* pq, const void* pg, 
   if (plan->method == SPR_NCC_FFT)
     return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w,
                            plan->geom.big ? plan->team_sync : nullptr, plan->ws, s);
+  if (plan->method == SPR_NCC_MFMA) return launch_pair_mfma(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
   return launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
 }

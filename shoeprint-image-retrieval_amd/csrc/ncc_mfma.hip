@@ -1,0 +1,394 @@
+// Direct-form NCC on the bf16 matrix cores: the scorer for SMALL feature maps stored as bfloat16 (ResNet50 layer3
+// and VGG16 conv5_3 shaped, cropped 28 x 12: BASELINE configs 3 and 5), where the FFT form spends its time on the
+// prepared spectra (15 KB per pair and channel against 0.7 KB of raw features).
+//
+// Per channel the numerator of similarity.py:48-55 is a product of a [queries x taps] with a [taps x positions] matrix:
+//     num[q, p] = sum_tap t0[q, tap] * I0z[p + tap]        (I0z = centred search map, zero outside: scipy 'same')
+//               = sum_tap t[q, tap] * I0z[p + tap] - mean(t[q]) * S1[p]         (S1 = window sum of I0z, :59)
+// A = the RAW template values: bfloat16 as stored, so every product below is exact.  B = I0z, which is not a bfloat16
+// number after centring: it enters as hi + lo (two bfloat16 numbers, 16 significant bits) and costs two MFMAs.
+// B is never materialised: it is a Toeplitz gather from the zero-padded map of the channel, kept in LDS in eight copies
+// shifted by one element each so that every lane's eight consecutive taps are one aligned ds_read_b128.
+// A fragment (8 taps of 16 positions) depends on (row of the position + row of the tap) only, so one fragment read
+// feeds up to NTG tiles of 16 positions, each against another template row pair: 78 fragment reads for 294 tile steps.
+//
+// One workgroup = one gallery item x 64 queries (one wave = 16 queries = the M side of v_mfma_f32_16x16x32_bf16), walking
+// the channels: per channel 2 x 294 MFMAs per wave, then per position  sum += a[q] * (b[p] * acc) - (a*mean)[q] * (b*S1)[p]
+// (a = 1/sqrt(sum t0^2), b = 1/sigma of the window, both float32 from float64 statistics as in the other methods),
+// channel sum in registers, spatial maximum and the running maximum over variants at the end (similarity.py:100-108,
+// :355-367).
+#include <type_traits>
+
+#include "ncc_prep_common.h"
+
+namespace spr {
+
+namespace {
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N) - register arrays indexed by I stay in registers
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int round_to_residue(int v, int modulus, int residue) {
+  int r = v - v % modulus + residue;
+  return r < v ? r + modulus : r;
+}
+
+template <int TH_, int TW_>
+struct MCfg {
+  static constexpr int TH = TH_, TW = TW_;  // cropped template = cropped search map
+  static constexpr int NPOS = TH * TW;
+  static constexpr int NTILE = NPOS / 16;      // tiles of 16 positions (row-major positions)
+  static constexpr int KS = TH / 2;            // k-steps: two template rows of 16 taps (TW padded to 16 with zeros)
+  static constexpr int TP = TW == 12 ? 3 : 2;  // tiles t and t + TP cover the same columns DY rows further down
+  static constexpr int DY = 16 * TP / TW;
+  static constexpr int NTG = NTILE / TP;
+  static constexpr int SMAX = DY * (NTG - 1) + 2 * (KS - 1);
+  static constexpr int PR = 2 * TH - 1;  // rows of the zero-padded map
+  static constexpr int CY = TH / 2, CX = TW / 2;
+  static_assert(NPOS % 16 == 0 && TH % 2 == 0 && NTILE % TP == 0 && DY % 2 == 0 && TW <= 16, "unsupported map size");
+  // LDS image of one channel: copy k (0..7) holds P shifted left by k elements, in chunks of 8 elements (16 bytes):
+  // chunk (copy k, chunk column jj, row r) at (k>>2)*CSG + (k&3)*16 + jj*JS + r*64; the residues of JS and CSG modulo
+  // 256 make the sixteen lanes of a fragment read hit sixteen different 16-byte bank groups.
+  static constexpr int JS = round_to_residue(PR * 64, 256, 128);
+  static constexpr int CSG = round_to_residue(3 * JS, 256, 192);
+  static constexpr int HL = 2 * CSG;  // lo plane behind the hi plane
+  static constexpr int kCopyBytes = 2 * HL;
+  static constexpr int kEbOff = kCopyBytes;                // float b[NPOS], (b*S1)[NPOS]
+  static constexpr int kBufBytes = kEbOff + 2 * 4 * NPOS;  // one channel; two buffers: channel c + 1 is staged under channel c
+  static constexpr int kLdsBytes = 2 * kBufBytes;
+  static_assert(kBufBytes % 16 == 0, "buffer alignment");
+  // prepared layouts
+  static constexpr int kQMapBytes = TH * 16 * 2;           // per channel: template rows padded to 16 taps (bf16)
+  static constexpr int kGChanBytes = 3 * 4 * NPOS;         // per channel: b, b*S1 (float), hi|lo (one word per pixel)
+};
+
+struct MfmaArgs {
+  int channels, nq, ng;
+  long long ld, col0;
+  int accumulate;
+  unsigned q_item_bytes, g_item_bytes;
+};
+
+__device__ __forceinline__ unsigned bf16_round(float v) {  // round to nearest even, finite inputs
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_value(unsigned bits) { return __uint_as_float(bits << 16); }
+
+// ---- preparation: grid = (channels, items) ---------------------------------------------------------------------------
+template <class M>
+__global__ void __launch_bounds__(kThreads)
+prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
+                 size_t item_bytes) {
+  unsigned char* lds = dyn_lds();
+  double* red = reinterpret_cast<double*>(lds);
+  float* x0 = reinterpret_cast<float*>(lds + 64);
+  double* sat1 = reinterpret_cast<double*>(lds + align_up(64 + sizeof(float) * M::NPOS, 16));
+  double* sat2 = sat1 + (M::TH + 1) * (M::TW + 1);
+  const int c = static_cast<int>(blockIdx.x);
+  const size_t item = blockIdx.y;
+  const int tid = static_cast<int>(threadIdx.x);
+  unsigned char* out_item = prepared + item * item_bytes;
+  if (is_query) {
+    const size_t base = (item * g.channels + c) * static_cast<size_t>(g.q_h) * g.q_w;
+    float mean;
+    load_centred(maps, base, g.q_w, g.crop, M::TH, M::TW, g.dtype, x0, red, &mean);
+    const float scale = template_scale(x0, M::NPOS, red);
+    // template rows as stored (bfloat16 bit patterns), padded to 16 taps
+    uint16_t* rows = reinterpret_cast<uint16_t*>(out_item + static_cast<size_t>(c) * M::kQMapBytes);
+    const uint16_t* raw = static_cast<const uint16_t*>(maps);
+    for (int i = tid; i < M::TH * 16; i += kThreads) {
+      const int u = i >> 4, v = i & 15;
+      rows[i] = v < M::TW ? raw[base + static_cast<size_t>(u + g.crop) * g.q_w + (v + g.crop)] : static_cast<uint16_t>(0);
+    }
+    if (tid == 0) {
+      float* sc = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kQMapBytes) + 2 * c;
+      sc[0] = scale;
+      sc[1] = scale * mean;
+    }
+  } else {
+    const size_t base = (item * g.channels + c) * static_cast<size_t>(g.g_h) * g.g_w;
+    load_centred(maps, base, g.g_w, g.crop, M::TH, M::TW, g.dtype, x0, red);
+    float* eb = reinterpret_cast<float*>(out_item + static_cast<size_t>(c) * M::kGChanBytes);
+    float* ebs = eb + M::NPOS;
+    unsigned* hl = reinterpret_cast<unsigned*>(ebs + M::NPOS);
+    for (int i = tid; i < M::NPOS; i += kThreads) {
+      const float v = x0[i];
+      const unsigned hi = bf16_round(v);
+      const unsigned lo = bf16_round(v - bf16_value(hi));
+      hl[i] = (hi << 16) | lo;
+    }
+    build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
+    const double inv_n = 1.0 / static_cast<double>(M::NPOS);
+    for (int i = tid; i < M::NPOS; i += kThreads) {
+      const int y = i / M::TW, x = i - y * M::TW;
+      const double s1 = window_sum(sat1, M::TH, M::TW, M::TH, M::TW, y, x);
+      const double s2 = window_sum(sat2, M::TH, M::TW, M::TH, M::TW, y, x);
+      const float inv = inv_sigma_from_sums(s1, s2, inv_n);
+      eb[i] = inv;
+      ebs[i] = inv * static_cast<float>(s1);
+    }
+  }
+}
+
+// ---- pair kernel: grid = (gallery items, blocks of 64 queries) ---------------------------------------------------------
+template <class M, bool MAPS>
+__global__ void __launch_bounds__(kThreads, 1)
+pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigned char* __restrict__ pg,
+                 float* __restrict__ scores, float* __restrict__ maps_out) {
+  unsigned char* lds = dyn_lds();
+  const int tid = static_cast<int>(threadIdx.x);
+  const int lane = tid & 63, wave = tid >> 6, col = lane & 15, kg = lane >> 4;
+  const size_t gi = blockIdx.x;
+  const int q0 = static_cast<int>(blockIdx.y) * 64;
+  const int nq_here = g.nq - q0 < 64 ? g.nq - q0 : 64;
+  const bool active = wave * 16 < nq_here;  // a wave without queries still stages the channel images
+
+  // the borders of the padded map stay zero for every channel
+  for (int i = tid; i < M::kLdsBytes / 16; i += kThreads) reinterpret_cast<float4*>(lds)[i] = float4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- gallery side: this lane stages pixels e0 = tid and e1 = tid + 256 of every channel ---------------------------
+  const unsigned char* g_item = pg + gi * static_cast<size_t>(g.g_item_bytes);
+  const bool has1 = tid + kThreads < M::NPOS;
+  const int e1 = has1 ? tid + kThreads : tid;
+  float st_b[2], st_bs[2];
+  unsigned st_hl[2];
+  auto stage_load = [&](int c) {
+    const float* cb = reinterpret_cast<const float*>(g_item + static_cast<size_t>(c) * M::kGChanBytes);
+    st_b[0] = cb[tid];                 st_b[1] = cb[e1];
+    st_bs[0] = cb[M::NPOS + tid];      st_bs[1] = cb[M::NPOS + e1];
+    st_hl[0] = __float_as_uint(cb[2 * M::NPOS + tid]);
+    st_hl[1] = __float_as_uint(cb[2 * M::NPOS + e1]);
+  };
+  // low half: byte offset of the pixel in copy 0 (row, column); high half: its column in the padded map
+  auto pixel_base = [&](int e) {
+    const int iy = e / M::TW, ix = e - iy * M::TW;
+    return ((iy + M::CY) * 64 + 2 * (ix + M::CX)) | ((ix + M::CX) << 16);
+  };
+  const int pb0 = pixel_base(tid), pb1 = pixel_base(e1);
+  auto stage_store_pixel = [&](unsigned char* buf, int pb, unsigned hl) {
+    const int w = pb >> 16, rowb = pb & 0xffff;
+    const uint16_t hi = static_cast<uint16_t>(hl >> 16), lo = static_cast<uint16_t>(hl & 0xffffu);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int mm = w - k;  // column of the pixel in copy k
+      if (k <= M::CX || mm >= 0) {  // w >= CX: only the far copies can push the first columns out
+        const int addr = (k >> 2) * M::CSG + (k & 3) * 16 - 2 * k + rowb + (M::JS - 16) * (mm >> 3);
+        *reinterpret_cast<uint16_t*>(buf + addr) = hi;
+        *reinterpret_cast<uint16_t*>(buf + addr + M::HL) = lo;
+      }
+    }
+  };
+  auto stage_store = [&](unsigned char* buf) {
+    float* eb = reinterpret_cast<float*>(buf + M::kEbOff);
+    stage_store_pixel(buf, pb0, st_hl[0]);
+    eb[tid] = st_b[0];
+    eb[M::NPOS + tid] = st_bs[0];
+    if (has1) {
+      stage_store_pixel(buf, pb1, st_hl[1]);
+      eb[e1] = st_b[1];
+      eb[M::NPOS + e1] = st_bs[1];
+    }
+  };
+
+  // ---- query side --------------------------------------------------------------------------------------------------
+  const unsigned char* q_block = pq + static_cast<size_t>(q0) * g.q_item_bytes;
+  const BufRsrc q_rs = make_rsrc(q_block, static_cast<size_t>(nq_here) * g.q_item_bytes);
+  auto clampq = [&](int q) { return q < nq_here ? q : nq_here - 1; };
+  const unsigned a_off = static_cast<unsigned>(clampq(wave * 16 + col)) * g.q_item_bytes + static_cast<unsigned>(kg) * 16u;
+  unsigned sc_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    sc_off[r] = static_cast<unsigned>(clampq(wave * 16 + 4 * kg + r)) * g.q_item_bytes +
+                static_cast<unsigned>(g.channels) * M::kQMapBytes;
+  auto load_a = [&](int c, int ks) { return buf_ld16v(q_rs, a_off, static_cast<unsigned>(c) * M::kQMapBytes + ks * 64); };
+
+  // fragment read addresses: tile phase ph covers positions 16*ph + col (+ 16*TP per tile group)
+  int frag_base[M::TP];
+#pragma unroll
+  for (int ph = 0; ph < M::TP; ++ph) {
+    const int p = 16 * ph + col, y = p / M::TW, x = p - y * M::TW;
+    const int m0 = x + 8 * (kg & 1), k = m0 & 7;
+    frag_base[ph] = (k >> 2) * M::CSG + (k & 3) * 16 + (m0 >> 3) * M::JS + (y + (kg >> 1)) * 64;
+  }
+
+  f32x4 run[M::NTILE];
+#pragma unroll
+  for (int t = 0; t < M::NTILE; ++t) run[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 A[M::KS];
+  if (active) {
+#pragma unroll
+    for (int ks = 0; ks < M::KS; ++ks) A[ks] = load_a(0, ks);
+  }
+  stage_load(0);
+  __syncthreads();  // the zero fill is complete
+  stage_store(lds);
+  stage_load(g.channels > 1 ? 1 : 0);
+  __syncthreads();
+
+  constexpr int NIT = (M::SMAX / 2 + 1) * M::TP;
+  constexpr int IT_STAGE = NIT / 3;  // where the next channel's image is written (its global loads are a third of a channel old)
+  for (int c = 0; c < g.channels; ++c) {
+    unsigned char* buf = lds + (c & 1) * M::kBufBytes;
+    unsigned char* buf_next = lds + ((c + 1) & 1) * M::kBufBytes;
+    const int cn = c + 1 < g.channels ? c + 1 : c;
+    const int cnn = c + 2 < g.channels ? c + 2 : c;
+    if (active) {
+      const float* eb = reinterpret_cast<const float*>(buf + M::kEbOff);
+      f32x2 sc[4];  // {a, a * mean} of this lane's four queries
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[r] = buf_ld8(q_rs, sc_off[r], static_cast<unsigned>(c) * 8u);
+      auto load_frag = [&](int ph, int s, int plane) {
+        return *reinterpret_cast<const u32x4*>(buf + frag_base[ph] + s * 64 + plane * M::HL);
+      };
+      f32x4 acc[M::NTILE];
+      auto epilogue = [&](int t) {
+        const float bt = eb[16 * t + col], bst = eb[M::NPOS + 16 * t + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = bt * acc[t][r];
+          run[t][r] = fmaf(-sc[r].y, bst, fmaf(sc[r].x, v, run[t][r]));
+          if constexpr (MAPS) {  // spr_ncc_maps: the channel's own map of the first query
+            if (r == 0 && wave == 0 && kg == 0)
+              maps_out[static_cast<size_t>(c) * M::NPOS + 16 * t + col] = fmaf(-sc[r].y, bst, sc[r].x * v);
+          }
+        }
+      };
+      // fragment ring: the reads of fragment it + kAhead are issued before the MFMAs of fragment it (the scheduling fences
+      // keep them there: left alone, the compiler sinks every read to just in front of its first use)
+      constexpr int kAhead = 4, kRing = 5;
+      u32x4 bh[kRing], bl[kRing];
+      static_for<0, kAhead>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        bh[j] = load_frag(j % M::TP, 2 * (j / M::TP), 0);
+        bl[j] = load_frag(j % M::TP, 2 * (j / M::TP), 1);
+      });
+      static_for<0, NIT>([&](auto it_c) {
+        constexpr int it = decltype(it_c)::value;
+        constexpr int s = 2 * (it / M::TP), ph = it % M::TP, slot = it % kRing;
+        if constexpr (it + kAhead < NIT) {
+          constexpr int s1 = 2 * ((it + kAhead) / M::TP), ph1 = (it + kAhead) % M::TP;
+          bh[(it + kAhead) % kRing] = load_frag(ph1, s1, 0);
+          bl[(it + kAhead) % kRing] = load_frag(ph1, s1, 1);
+        }
+        sched_fence();
+        if constexpr (it > 0) {  // the tile finished by the previous fragment (its MFMAs have had time to drain)
+          constexpr int sp = 2 * ((it - 1) / M::TP), php = (it - 1) % M::TP;
+          constexpr int d = sp - 2 * (M::KS - 1);
+          if constexpr (d >= 0 && d % M::DY == 0 && d / M::DY < M::NTG) epilogue((d / M::DY) * M::TP + php);
+        }
+        if constexpr (it == IT_STAGE) {
+          stage_store(buf_next);
+          stage_load(cnn);
+        }
+        static_for<0, M::NTG>([&](auto tg_c) {
+          constexpr int tg = decltype(tg_c)::value;
+          constexpr int k2 = s - M::DY * tg;
+          if constexpr (k2 >= 0 && k2 < 2 * M::KS) {
+            constexpr int ks = k2 / 2, t = tg * M::TP + ph;
+            if constexpr (ks == 0)
+              acc[t] = mfma_bf16_16x16x32(A[ks], bh[slot], f32x4{0.f, 0.f, 0.f, 0.f});
+            else
+              acc[t] = mfma_bf16_16x16x32(A[ks], bh[slot], acc[t]);
+            acc[t] = mfma_bf16_16x16x32(A[ks], bl[slot], acc[t]);
+            // the last use of this template row pair in the channel: fetch the next channel's into the same registers
+            if constexpr (tg == M::NTG - 1 && ph == M::TP - 1) A[ks] = load_a(cn, ks);
+          }
+        });
+        sched_fence();
+      });
+      epilogue((M::NTG - 1) * M::TP + M::TP - 1);
+    } else {
+      stage_store(buf_next);
+      stage_load(cnn);
+    }
+    __syncthreads();  // channel c + 1 is staged; nobody reads channel c's image any more
+  }
+
+  if (!active || !scores) return;  // spr_ncc_maps passes no score matrix
+  // spatial maximum per query: over this lane's tiles, then over the sixteen lanes holding the other positions
+  float best[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    best[r] = run[0][r];
+#pragma unroll
+    for (int t = 1; t < M::NTILE; ++t) best[r] = fmaxf(best[r], run[t][r]);
+    for (int m = 8; m >= 1; m >>= 1) best[r] = fmaxf(best[r], shfl_xor(best[r], m));
+  }
+  if (col == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = wave * 16 + 4 * kg + r;
+      if (q < nq_here) {
+        const float s = best[r] / static_cast<float>(g.channels);
+        float* dst = scores + static_cast<size_t>(q0 + q) * g.ld + g.col0 + gi;
+        const float prev = g.accumulate ? *dst : 0.0f;
+        *dst = s > prev ? s : prev;  // similarity.py:355, 366-367: zero-initialised running maximum
+      }
+    }
+  }
+}
+
+using M2812 = MCfg<28, 12>;
+
+bool mfma_shape_ok(const NccGeom& g) {
+  return g.dtype == SPR_BF16 && g.th == M2812::TH && g.tw == M2812::TW && g.ih == M2812::TH && g.iw == M2812::TW;
+}
+
+}  // namespace
+
+bool mfma_geometry(const NccGeom& g) {
+  if (!mfma_shape_ok(g)) return false;
+  // buffer-load offsets of a 64-query block and the scalar channel offsets are 32-bit
+  return static_cast<size_t>(g.channels) * (M2812::kQMapBytes + 8) * 64 < (static_cast<size_t>(1) << 31);
+}
+
+size_t mfma_query_item_bytes(const NccGeom& g) {
+  return align_up(static_cast<size_t>(g.channels) * (M2812::kQMapBytes + 8), 256);
+}
+size_t mfma_gallery_item_bytes(const NccGeom& g) {
+  return align_up(static_cast<size_t>(g.channels) * M2812::kGChanBytes, 256);
+}
+
+int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream) {
+  if (n == 0) return SPR_OK;
+  using M = M2812;
+  const size_t lds = align_up(64 + sizeof(float) * M::NPOS, 16) + 2 * sizeof(double) * (M::TH + 1) * (M::TW + 1);
+  const size_t item_bytes = is_query ? mfma_query_item_bytes(g) : mfma_gallery_item_bytes(g);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_mfma_kernel<M>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads), lds,
+                     stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes);
+  return check_launch("prep_mfma_kernel");
+}
+
+int launch_pair_mfma(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
+                     int64_t col0, int accumulate, float* maps_out, hipStream_t stream) {
+  if (nq == 0 || ng == 0) return SPR_OK;
+  using M = M2812;
+  auto kernel = maps_out ? pair_mfma_kernel<M, true> : pair_mfma_kernel<M, false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+  const unsigned q_blocks = static_cast<unsigned>((nq + 63) / 64);
+  const size_t g_item = mfma_gallery_item_bytes(g);
+  // HIP refuses a grid of 2^32 work-items or more: slices of the gallery
+  int64_t max_g = pair_tiles_per_launch(1, kThreads) / q_blocks;
+  if (max_g < 1) max_g = 1;
+  for (int64_t g0 = 0; g0 < ng; g0 += max_g) {
+    const int64_t n = ng - g0 < max_g ? ng - g0 : max_g;
+    MfmaArgs a{g.channels, static_cast<int>(nq), static_cast<int>(n), static_cast<long long>(ld),
+               static_cast<long long>(col0 + g0), accumulate, static_cast<unsigned>(mfma_query_item_bytes(g)),
+               static_cast<unsigned>(g_item)};
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n), q_blocks), dim3(kThreads),
+                       M::kLdsBytes, stream, a, static_cast<const unsigned char*>(pq),
+                       static_cast<const unsigned char*>(pg) + static_cast<size_t>(g0) * g_item, scores, maps_out);
+    const int rc = check_launch("pair_mfma_kernel");
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
+}
+
+}  // namespace spr

@@ -14,7 +14,7 @@ __device__ __forceinline__ int wg_size() { return static_cast<int>(blockDim.x); 
 // x0[y*w + x] = crop(map)[y][x] - mean(crop(map)), float32 arithmetic on a float64-accumulated mean.
 // Returns after a workgroup barrier.
 __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base, int raw_w, int crop, int h, int w,
-                                             int dtype, float* x0, double* red) {
+                                             int dtype, float* x0, double* red, float* mean_out = nullptr) {
   const int tid = static_cast<int>(threadIdx.x);
   const int n = h * w;
   double s = 0.0;
@@ -47,6 +47,7 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
   const double total = block_sum(s, red);
   const float mean = static_cast<float>(total / static_cast<double>(n));
   for (int i = tid; i < n; i += wg_size()) x0[i] = x0[i] - mean;
+  if (mean_out) *mean_out = mean;
   __syncthreads();
 }
 

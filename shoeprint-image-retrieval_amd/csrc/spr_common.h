@@ -87,6 +87,13 @@ int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg
                     int64_t ld, int64_t col0, int accumulate, float* maps_out, const cf* tw_h, const cf* tw_w,
                     unsigned* team_sync, const FftWorkspace& ws,
                     hipStream_t stream);  // team_sync: 8 x 32 counters, or null (tile mode only)
+// direct form on the bf16 matrix cores (ncc_mfma.hip): small maps stored as bfloat16
+bool mfma_geometry(const NccGeom& g);  // true if an instantiated kernel covers this plan
+size_t mfma_query_item_bytes(const NccGeom& g);
+size_t mfma_gallery_item_bytes(const NccGeom& g);
+int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream);
+int launch_pair_mfma(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
+                     int64_t col0, int accumulate, float* maps_out, hipStream_t stream);
 bool fft_geometry(NccGeom& g, bool pow2_only);  // fills the FFT fields; false if no instantiated kernel fits
 bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps do not fit LDS
 

@@ -10,6 +10,7 @@ constexpr int kWave = 64;  // CDNA wavefront width
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Base of the dynamic LDS allocation (16-byte aligned; no static __shared__ precedes it).
 extern __shared__ __attribute__((aligned(16))) unsigned char spr_lds_raw[];
@@ -75,9 +76,11 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* uniform_base, size_t by
   return BufRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, static_cast<int>(bytes), 0x00020000)};
 }
 __device__ __forceinline__ float4 buf_ld16(BufRsrc rs, unsigned lane_off, unsigned uniform_off) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs.r, static_cast<int>(lane_off), static_cast<int>(uniform_off), 0);
   return __builtin_bit_cast(float4, v);
+}
+__device__ __forceinline__ u32x4 buf_ld16v(BufRsrc rs, unsigned lane_off, unsigned uniform_off) {  // as a native vector
+  return __builtin_amdgcn_raw_buffer_load_b128(rs.r, static_cast<int>(lane_off), static_cast<int>(uniform_off), 0);
 }
 __device__ __forceinline__ f32x2 buf_ld8(BufRsrc rs, unsigned lane_off, unsigned uniform_off) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -198,6 +201,14 @@ __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
 // D[(j&3) + 8*(j>>2) + 4*(l>>5)][l&31], j = 0..15.
 __device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// D = A(16x32) * B(32x16) + C on the bf16 matrix cores (exact products, f32 accumulation).  Lane l supplies, as eight
+// bf16 bit patterns packed in four dwords (element j in the low / high half of dword j/2), A[l&15][8*(l>>4) + j] and
+// B[8*(l>>4) + j][l&15]; it owns D[(l>>4)*4 + r][l&15], r = 0..3.
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 }  // namespace spr

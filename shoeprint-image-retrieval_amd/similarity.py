@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import NCC_AUTO, NCC_DIRECT, NCC_FFT, NccShape
 
 CROP = 2  # similarity.py:92-93
-_METHODS = {"auto": NCC_AUTO, "fft": NCC_FFT, "direct": NCC_DIRECT, "fft_pow2": _lib.NCC_FFT_POW2}
+_METHODS = {"auto": NCC_AUTO, "fft": NCC_FFT, "direct": NCC_DIRECT, "fft_pow2": _lib.NCC_FFT_POW2, "mfma": _lib.NCC_MFMA}
 _DTYPES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float16): _lib.F16}
 
 
@@ -89,7 +89,7 @@ class NccScorer:
     ----------
     device : backend object (default ``TorchDevice()``: PyTorch-ROCm on the current GPU)
     library: ``_lib.Library`` (default: the in-tree libshoeprint_mi355x.so)
-    method : "auto" | "fft" | "direct"  (pair-kernel choice, see the C header)
+    method : "auto" | "fft" | "direct" | "fft_pow2" | "mfma"  (pair-kernel choice, see the C header)
     max_prepared_bytes: HBM budget for the prepared form of one gallery chunk (default: a third
         of the free memory, at most 64 GiB); larger galleries are processed chunk by chunk.
     storage: HBM storage type of feature batches uploaded from host lists ("float32" | "float16" | "bfloat16");
@@ -334,7 +334,7 @@ _config_scorers: dict[tuple, NccScorer] = {}
 
 
 def scorer_from_config(config: dict, *, device=None, library: _lib.Library | None = None) -> NccScorer:
-    """The scorer that ``[mi355x]`` of run.toml asks for: ``ncc_method`` ("auto" | "fft" | "fft_pow2" | "direct"),
+    """The scorer that ``[mi355x]`` of run.toml asks for: ``ncc_method`` ("auto" | "fft" | "fft_pow2" | "direct" | "mfma"),
     ``dtype`` (HBM storage type of the feature maps: "float32" | "float16" | "bfloat16") and ``max_prepared_gib`` (HBM
     budget of one prepared gallery chunk; 0 = automatic).  Reference files, which have no such table, get the defaults."""
     extra = config.get("mi355x") or {}

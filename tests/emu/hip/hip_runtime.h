@@ -82,7 +82,7 @@ struct BlockCtx {
   std::function<void()> body;
   unsigned char* lds = nullptr;
   std::vector<uint64_t> xchg;  // one 8-byte slot per work-item for cross-lane ops
-  std::vector<float> xf;       // scratch for emulated MFMA operands: 2 floats per work-item
+  std::vector<float> xf;       // scratch for emulated MFMA operands: 8 floats (two 16-byte fragments) per work-item
 };
 
 inline thread_local BlockCtx* t_blk = nullptr;
@@ -113,7 +113,7 @@ inline void run_block(BlockCtx& b, dim3 block) {
   }
   b.nthreads = n;
   b.xchg.assign(n, 0);
-  b.xf.assign(2 * static_cast<size_t>(n), 0.f);
+  b.xf.assign(8 * static_cast<size_t>(n), 0.f);
   t_blk = &b;
   for (int i = 0; i < n; ++i) {
     Fiber& f = b.fibers[i];
@@ -257,6 +257,8 @@ static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return 
 
 // ---------------------------------------------------------------- device-side helpers
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

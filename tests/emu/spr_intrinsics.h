@@ -8,6 +8,7 @@ constexpr int kWave = 64;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 inline unsigned char* dyn_lds() { return hipemu::t_blk->lds; }
 
@@ -59,6 +60,12 @@ inline void buf_check(const BufRsrc& r, unsigned lane_off, unsigned n) {
     std::fprintf(stderr, "hipemu: buffer load outside its descriptor (lane offset %u + %u > %zu)\n", lane_off, n, r.bytes);
     std::abort();
   }
+}
+inline u32x4 buf_ld16v(BufRsrc r, unsigned lane_off, unsigned uniform_off) {
+  buf_check(r, lane_off, 16);
+  u32x4 v;
+  std::memcpy(&v, r.base + lane_off + uniform_off, 16);
+  return v;
 }
 inline float4 buf_ld16(BufRsrc r, unsigned lane_off, unsigned uniform_off) {
   buf_check(r, lane_off, 16);
@@ -114,15 +121,15 @@ inline int uniform(int v) { return v; }
 inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
   hipemu::BlockCtx* blk = hipemu::t_blk;
   const int me = blk->cur, w0 = me & ~(kWave - 1), l = me - w0;
-  blk->xf[2 * me] = a;
-  blk->xf[2 * me + 1] = b;
+  blk->xf[8 * me] = a;
+  blk->xf[8 * me + 1] = b;
   hipemu::yield(hipemu::WAIT_WAVE);
   f32x4 d = c;
   const int col = l & 15;
   for (int j = 0; j < 4; ++j) {
     const int row = (l >> 4) * 4 + j;
     float acc = c[j];
-    for (int k = 0; k < 4; ++k) acc = std::fmaf(blk->xf[2 * (w0 + row + 16 * k)], blk->xf[2 * (w0 + col + 16 * k) + 1], acc);
+    for (int k = 0; k < 4; ++k) acc = std::fmaf(blk->xf[8 * (w0 + row + 16 * k)], blk->xf[8 * (w0 + col + 16 * k) + 1], acc);
     d[j] = acc;
   }
   hipemu::yield(hipemu::WAIT_WAVE);
@@ -131,16 +138,44 @@ inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
 inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
   hipemu::BlockCtx* blk = hipemu::t_blk;
   const int me = blk->cur, w0 = me & ~(kWave - 1), l = me - w0;
-  blk->xf[2 * me] = a;
-  blk->xf[2 * me + 1] = b;
+  blk->xf[8 * me] = a;
+  blk->xf[8 * me + 1] = b;
   hipemu::yield(hipemu::WAIT_WAVE);
   f32x16 d = c;
   const int col = l & 31;
   for (int j = 0; j < 16; ++j) {
     const int row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5);
     float acc = c[j];
-    for (int k = 0; k < 2; ++k) acc = std::fmaf(blk->xf[2 * (w0 + row + 32 * k)], blk->xf[2 * (w0 + col + 32 * k) + 1], acc);
+    for (int k = 0; k < 2; ++k) acc = std::fmaf(blk->xf[8 * (w0 + row + 32 * k)], blk->xf[8 * (w0 + col + 32 * k) + 1], acc);
     d[j] = acc;
+  }
+  hipemu::yield(hipemu::WAIT_WAVE);
+  return d;
+}
+
+// bf16 MFMA: every lane publishes its two 16-byte fragments; products of bf16 values are exact in float, the
+// accumulation is a k-ordered float chain (the hardware's internal order is not documented: tests use tolerances)
+inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+  hipemu::BlockCtx* blk = hipemu::t_blk;
+  const int me = blk->cur, w0 = me & ~(kWave - 1), l = me - w0;
+  std::memcpy(&blk->xf[8 * me], &a, 16);
+  std::memcpy(&blk->xf[8 * me + 4], &b, 16);
+  hipemu::yield(hipemu::WAIT_WAVE);
+  auto elem = [&](int lane, int which, int j) {
+    uint16_t bits;
+    std::memcpy(&bits, reinterpret_cast<const char*>(&blk->xf[8 * (w0 + lane) + 4 * which]) + 2 * j, 2);
+    const uint32_t u = static_cast<uint32_t>(bits) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  f32x4 d = c;
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) acc += elem(row + 16 * (k >> 3), 0, k & 7) * elem(col + 16 * (k >> 3), 1, k & 7);
+    d[r] = acc;
   }
   hipemu::yield(hipemu::WAIT_WAVE);
   return d;

@@ -10,6 +10,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from oracle import ncc_oracle as oracle
 from shoeprint_image_retrieval_amd import similarity, synth
@@ -141,6 +142,65 @@ def check_config3_bf16_resnet_layer3(scorer, channels):
     ref = oracle.similarity_matrix(list(synth.from_bfloat16_bits(qb)), list(synth.from_bfloat16_bits(gb)), precise=True)
     np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
     assert (got.argmax(axis=1) == np.arange(nq)).all()  # each query still finds its own print
+
+
+def _bf16_sets(seed, channels, nq, ng):
+    g = [np.maximum(synth.gallery_features(seed, i, channels, 32, 16), 0) for i in range(ng)]
+    q = [np.maximum(synth.query_features(seed, i % ng, i, channels, 32, 16), 0) for i in range(nq)]
+    qb, gb = synth.bfloat16_bits(np.stack(q)), synth.bfloat16_bits(np.stack(g))
+    return qb, gb, list(synth.from_bfloat16_bits(qb)), list(synth.from_bfloat16_bits(gb))
+
+
+def check_mfma_method(make_scorer, channels, nq, ng, tol=TIGHT):
+    """The matrix-core direct form (ncc_mfma.hip) on ResNet50-layer3-shaped bfloat16 maps: chosen by "auto", scores equal to
+    the oracle on the rounded features, query counts that leave waves and lanes of the last 64-query block without work,
+    the running maximum over variants, and the per-channel maps of spr_ncc_maps."""
+    from shoeprint_image_retrieval_amd import _lib
+
+    qb, gb, qf, gf = _bf16_sets(43, channels, nq, ng)
+    sc = make_scorer("auto")
+    dev = sc.dev
+    plan = sc.plan(channels, (32, 16), (32, 16), dtype="bfloat16")
+    assert plan.method == _lib.NCC_MFMA
+    got = dev.to_host(sc.scores_device(dev.to_device(qb), dev.to_device(gb)))
+    ref = oracle.similarity_matrix(qf, gf, precise=True)
+    np.testing.assert_allclose(got, ref, atol=tol, rtol=0)
+    # running maximum (similarity.py:364-367): a second pass over other queries keeps the larger score
+    scores = dev.to_device(np.full((nq, ng), 0.05, np.float32))
+    sc.scores_device(dev.to_device(qb), dev.to_device(gb), scores=scores, accumulate_max=True)
+    np.testing.assert_allclose(dev.to_host(scores), np.maximum(ref, 0.05), atol=tol, rtol=0)
+    # per-channel maps of one pair
+    pq = sc.prepare_queries(plan, dev.to_device(qb[:1]))
+    pg = sc.prepare_gallery(plan, dev.to_device(gb[1:2]))
+    maps = dev.to_host(sc.ncc_maps_device(plan, pq, pg))
+    want = np.stack([oracle.normxcorr(qf[0][c, 2:-2, 2:-2], gf[1][c, 2:-2, 2:-2], precise=True) for c in range(channels)])
+    np.testing.assert_allclose(maps, want, atol=20 * tol, rtol=0)
+    # other shapes and storage types stay with the other methods; asking for the method outright is refused there
+    assert sc.plan(channels, (30, 16), (32, 16), dtype="bfloat16").method != _lib.NCC_MFMA
+    assert sc.plan(channels, (32, 16), (32, 16), dtype=np.float32).method != _lib.NCC_MFMA
+    with pytest.raises(Exception, match="matrix-core"):
+        make_scorer("mfma").plan(channels, (32, 16), (32, 16), dtype=np.float32)
+
+
+def check_mfma_large_gallery(make_scorer, monkeypatch, channels, nq, ng, oracle_pairs=12):
+    qb, gb, qf, gf = _bf16_sets(47, channels, nq, ng)
+    mf, ff = make_scorer("mfma"), make_scorer("fft")
+    dev = mf.dev
+    qd, gd = dev.to_device(qb), dev.to_device(gb)
+    got = dev.to_host(mf.scores_device(qd, gd))
+    other = dev.to_host(ff.scores_device(qd, gd))
+    np.testing.assert_allclose(got, other, atol=TIGHT, rtol=0)
+    rng = np.random.default_rng(5)
+    for qi, gi in zip(rng.integers(0, nq, oracle_pairs), rng.integers(0, ng, oracle_pairs)):
+        want = float(oracle.get_similarity(qf[qi], gf[gi], precise=True))
+        assert abs(got[qi, gi] - max(want, 0.0)) <= TIGHT, (qi, gi, got[qi, gi], want)
+    match = dev.to_device((np.arange(nq) % ng).astype(np.int32))
+    r_m = dev.to_host(mf.ranks_device(dev.to_device(got), match))
+    r_f = dev.to_host(ff.ranks_device(dev.to_device(other), match))
+    np.testing.assert_array_equal(r_m, r_f)
+    monkeypatch.setenv("SPR_NCC_MAX_TILES", str(max(1, ng // 3)))  # three launches over the gallery
+    np.testing.assert_array_equal(dev.to_host(mf.scores_device(qd, gd)), got)
+    monkeypatch.delenv("SPR_NCC_MAX_TILES")
 
 
 def check_config5_multi_layer_fp16(scorer, channels):

@@ -153,6 +153,11 @@ def test_emu_reduced_precision_configs():
     pc.check_config5_multi_layer_fp16(sc, channels=(2, 4, 4))
 
 
+@pytest.mark.parametrize("channels,nq,ng", [(3, 5, 2), (2, 70, 2), (2, 17, 3)])
+def test_emu_matrix_core_method(channels, nq, ng):
+    pc.check_mfma_method(emu_scorer, channels, nq, ng)
+
+
 # ------------------------------------------------------------------------- real library: ABI only
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "shoeprint_mi355x.h")).read()

@@ -75,6 +75,23 @@ def test_config3_bf16_resnet_layer3_maps(fft_scorer):
     pc.check_config3_bf16_resnet_layer3(fft_scorer, channels=1024)
 
 
+def _make_scorer(lib):
+    from shoeprint_image_retrieval_amd.similarity import NccScorer
+
+    return lambda method: NccScorer(method=method, library=lib)
+
+
+@pytest.mark.parametrize("channels,nq,ng", [(1024, 5, 3), (64, 70, 4), (16, 129, 2)])
+def test_matrix_core_method(lib, channels, nq, ng):
+    pc.check_mfma_method(_make_scorer(lib), channels, nq, ng)
+
+
+def test_matrix_core_method_large_gallery(lib, monkeypatch):
+    """G = 1 000 at the full ResNet50-layer3 shape [1024,32,16] bfloat16 (BASELINE config 3 in shape): the matrix-core form
+    against the FFT form on every pair, against the oracle on sampled pairs, identical ranks, launches sliced."""
+    pc.check_mfma_large_gallery(_make_scorer(lib), monkeypatch, channels=1024, nq=8, ng=1000)
+
+
 def test_config5_multi_layer_fp16(fft_scorer):
     pc.check_config5_multi_layer_fp16(fft_scorer, channels=(256, 512, 512))
 
