@@ -74,15 +74,19 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
   unsigned char* item_base = prepared + item * item_bytes;
   cf* spec = reinterpret_cast<cf*>(item_base) + static_cast<size_t>(c) * C::kSpecPerChan;
 
-  if (!is_query) {
+  // the six-wave layout with both tables in LDS writes its 1/sigma slots in slot order, zeros included (below)
+  const bool inv_by_slot = C::SIX && sat2_off != 0 && sat_blocked_fits(h, w);
+  if (!is_query && !inv_by_slot) {
     // 1/sigma slots that no pixel maps to (rows >= ih, columns >= iw, surplus lanes) must read as 0: clear the
     // channel's slot first; the workgroup barriers below order these stores before the values written later
     float4* inv4 = reinterpret_cast<float4*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
                    static_cast<size_t>(c) * (g.inv_per_chan / 4);
     for (int i = tid; i < g.inv_per_chan / 4; i += PT) inv4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
   }
+  SPR_PSTAMP(0);
   load_centred(maps, (item * g.channels + c) * static_cast<size_t>(raw_h) * raw_w, raw_w, g.crop, h, w, g.dtype, x0,
                red);
+  SPR_PSTAMP(1);
   float scale = 1.0f;
   {
     // dead flag of this (item, channel): a constant channel - all zero after ReLU, typically - has a zero centred map,
@@ -94,6 +98,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     if (tid == 0) flags[c] = rs == 0.0f ? 1 : 0;
     if (is_query) scale = rs * (1.0f / (static_cast<float>(C::NH) * static_cast<float>(C::NW)));
   }
+  SPR_PSTAMP(2);
   if (!is_query) {
     // 1/sigma map in the pair kernel's register order; slots no pixel maps to stay 0.
     float* inv = reinterpret_cast<float*>(item_base + sizeof(cf) * static_cast<size_t>(g.channels) * C::kSpecPerChan) +
@@ -112,13 +117,54 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
       const int lane = giw * C::TGW + t;
       inv[((rr * (nv / 4) + (e2 >> 2)) * C::NT + lane) * 4 + (e2 & 3)] = v;
     };
-    if (sat2_off != 0) {
+    if (inv_by_slot) {
+      // One float4 per (sub-transform set, pair-kernel lane) = the 1/sigma values of the four pixels that lane weights:
+      // every slot is written exactly once, in address order (16 bytes per work-item, coalesced), zeros where no pixel
+      // maps to it.  Inverse of Cfg::inv6_index.
+      double* sat2 = reinterpret_cast<double*>(big + sat2_off);
+      build_sat_pair_blocked(x0, h, w, sat, sat2);
+      SPR_PSTAMP(8);
+      const double inv_n = 1.0 / (static_cast<double>(g.th) * static_cast<double>(g.tw));
+      const int stride = w + 1;
+      float4* inv4 = reinterpret_cast<float4*>(inv);
+      for (int idx4 = tid; idx4 < C::kInv6PerChan / 4; idx4 += PT) {
+        const int pp = idx4 / C::NT, lane6 = idx4 - pp * C::NT;
+        const int l64 = lane6 & 63, rg = l64 / 3, tq = l64 - 3 * rg;
+        const int row = (lane6 >> 6) * C::kRowGroups + rg, n1 = 3 * pp + tq;
+        float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (l64 < 63 && n1 < 16 && row < h) {
+          const int b = (33 * n1) % 48;
+          const int ma = tq == 1 ? b - 32 : b, mb = ma == n1 ? n1 + 16 : n1;
+          int y0 = row - g.th / 2, y1 = y0 + g.th;
+          y0 = y0 < 0 ? 0 : (y0 > h ? h : y0);
+          y1 = y1 > h ? h : (y1 < 0 ? 0 : y1);
+          const double* t1a = sat + static_cast<size_t>(y1) * stride;
+          const double* t1b = sat + static_cast<size_t>(y0) * stride;
+          const double* t2a = sat2 + static_cast<size_t>(y1) * stride;
+          const double* t2b = sat2 + static_cast<size_t>(y0) * stride;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int x = 2 * (e < 2 ? ma : mb) + (e & 1);
+            if (x >= w) continue;
+            int xa = x - g.tw / 2, xb = xa + g.tw;
+            xa = xa < 0 ? 0 : (xa > w ? w : xa);
+            xb = xb > w ? w : (xb < 0 ? 0 : xb);
+            const double s1 = t1a[xb] - t1b[xb] - t1a[xa] + t1b[xa];
+            const double s2 = t2a[xb] - t2b[xb] - t2a[xa] + t2b[xa];
+            o[e] = inv_sigma_from_sums(s1, s2, inv_n);
+          }
+        }
+        inv4[idx4] = float4{o[0], o[1], o[2], o[3]};
+      }
+      __syncthreads();
+    } else if (sat2_off != 0) {
       inv_sigma_map_fused(x0, h, w, g.th, g.tw, sat, reinterpret_cast<double*>(big + sat2_off), store);
     } else {
       inv_sigma_map(x0, h, w, g.th, g.tw, sat, [&](int i, float v) { store(i / w, i % w, v); });
     }
   }
 
+  SPR_PSTAMP(3);
   // ---- row pass: two real rows per complex transform of length NW -------------------------------
   {
     const int giw = tid / C::TGW, t = tid - giw * C::TGW;
@@ -162,6 +208,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
     }
   }
   __syncthreads();
+  SPR_PSTAMP(4);
 
   // ---- column pass: nw/2 + 1 columns of length NH ----------------------------------------------
   {
@@ -210,6 +257,7 @@ prep_fft_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned
       }
     }
   }
+  SPR_PSTAMP(5);
 }
 
 // ============================================================================================
@@ -981,5 +1029,11 @@ int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg
   if (!e) { set_error("no FFT kernel for grid %dx%d", g.nh, g.nw); return SPR_ERR_UNSUPPORTED; }
   return e->pair(g, g.tight != 0, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, tw_h, tw_w, team_sync, ws, stream);
 }
+
+#ifdef SPR_PREP_STAMPS
+extern "C" int spr_debug_read_prep_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prep_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace spr

@@ -6,6 +6,15 @@
 
 namespace spr {
 
+// -DSPR_PREP_STAMPS (ncc_fft.hip only): diagnostic build for tools/ubench/stamps_prep.py - one workgroup of the FFT prep
+// kernel records the shader clock at its phase boundaries
+#ifdef SPR_PREP_STAMPS
+__device__ unsigned long long g_prep_stamps[16];
+#define SPR_PSTAMP(i) do { if (blockIdx.x == 100 && blockIdx.y == 700 && threadIdx.x == 0) g_prep_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPR_PSTAMP(i)
+#endif
+
 constexpr int kMaxPixPerThread = 48;  // two-sweep 1/sigma path: cropped maps of up to 48 pixels per work-item
 
 // All helpers here run on whatever workgroup size the kernel was launched with (a multiple of 64).
@@ -19,11 +28,12 @@ __device__ __forceinline__ void load_centred(const void* maps, size_t chan_base,
   const int n = h * w;
   double s = 0.0;
   // (y, x) of pixel i = tid + k*wg_size() advance incrementally: one division per lane, not per pixel.
-  // Eight loads are requested before the first is used, so a lane waits for HBM/L2 once per batch, not per pixel.
+  // Sixteen loads are requested before the first is used, so a lane waits for HBM/L2 once per batch, not per pixel
+  // (a conv3_3 map on 512 work-items is one batch).
   const int nthr = wg_size();
   const int dy = nthr / w, dx = nthr - dy * w;
   int y = tid / w, x = tid - y * w;
-  constexpr int B = 8;
+  constexpr int B = 16;
   for (int i0 = tid; i0 < n; i0 += B * nthr) {
     float v[B];
     int yy = y, xx = x;
@@ -170,6 +180,154 @@ __device__ __forceinline__ void build_sat_pair(const float* __restrict__ x0, int
   __syncthreads();
 }
 
+// The same two tables with every scan cut into kSatSeg segments: a row (column) is scanned by kSatSeg work-items, each from
+// zero over its own stretch, then the totals of the stretches before it are added - four times as many work-items on chains
+// a quarter as long (the serial form keeps h (2w + 2) work-items of the workgroup busy, the rest wait at the barrier).
+// The float64 sums are formed in another order than build_sat_pair's: differences of a few ulp of float64.
+constexpr int kSatSeg = 4;
+constexpr int kSatRowSeg = 16;  // longest row stretch the register batches below hold (w <= 64)
+__device__ __forceinline__ bool sat_blocked_fits(int h, int w) {
+  return h * kSatSeg <= 2 * wg_size() && 2 * kSatSeg * w <= 4 * wg_size() && (w + kSatSeg - 1) / kSatSeg <= kSatRowSeg;
+}
+__device__ __forceinline__ void build_sat_pair_blocked(const float* __restrict__ x0, int h, int w, double* __restrict__ sat1,
+                                                       double* __restrict__ sat2) {
+  // No element is predicated: a batch slot beyond the end of a stretch re-reads and re-writes the stretch's LAST element
+  // (its addend is 0, so the value written again is the same), which costs far fewer instructions than masking it.
+  const int tid = static_cast<int>(threadIdx.x), nthr = wg_size();
+  const int stride = w + 1;
+  const int wseg = (w + kSatSeg - 1) / kSatSeg, hseg = (h + kSatSeg - 1) / kSatSeg;
+  for (int x = tid; x <= w; x += nthr) { sat1[x] = 0.0; sat2[x] = 0.0; }
+  // ---- rows: unit (y, stretch); every LDS round trip is paid once per register batch, not once per element ----
+  for (int u = tid; u < h * kSatSeg; u += nthr) {
+    const int y = u / kSatSeg, sg = u - y * kSatSeg;
+    const int xa = sg * wseg, last = (xa + wseg < w ? xa + wseg : w) - xa - 1;
+    if (last < 0) continue;  // narrow maps: a stretch past the last column
+    double* row1 = sat1 + (y + 1) * stride + xa + 1;
+    double* row2 = sat2 + (y + 1) * stride + xa + 1;
+    const float* src = x0 + y * w + xa;
+    float v[kSatRowSeg];
+#pragma unroll
+    for (int k = 0; k < kSatRowSeg; ++k) {
+      const float t = src[k < last ? k : last];
+      v[k] = k <= last ? t : 0.0f;
+    }
+    if (sg == 0) { row1[-1] = 0.0; row2[-1] = 0.0; }
+    double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSatRowSeg; ++k) {
+      const float sq = v[k] * v[k];  // np.square keeps float32 (similarity.py:57)
+      r1 += static_cast<double>(v[k]);
+      r2 += static_cast<double>(sq);
+      const int kk = k < last ? k : last;
+      row1[kk] = r1; row2[kk] = r2;
+    }
+  }
+  __syncthreads();
+  {
+    // totals of the stretches before this one (read by everybody before anybody adds: two barriers)
+    double o1[2], o2[2];  // a workgroup of 256 covers h * kSatSeg <= 512 units in two turns
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = tid + k * nthr < h * kSatSeg ? tid + k * nthr : h * kSatSeg - 1;
+      const int y = u / kSatSeg, sg = u - y * kSatSeg;
+      const double* row1 = sat1 + (y + 1) * stride;
+      const double* row2 = sat2 + (y + 1) * stride;
+      o1[k] = 0.0; o2[k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < kSatSeg - 1; ++j) {
+        const int e = (j + 1) * wseg < w ? (j + 1) * wseg : w;
+        const double a1 = row1[e], a2 = row2[e];
+        o1[k] += j < sg ? a1 : 0.0;
+        o2[k] += j < sg ? a2 : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = tid + k * nthr;
+      if (u >= h * kSatSeg) continue;
+      const int y = u / kSatSeg, sg = u - y * kSatSeg;
+      if (sg == 0) continue;
+      const int xa = sg * wseg, last = (xa + wseg < w ? xa + wseg : w) - xa - 1;
+      if (last < 0) continue;
+      double* row1 = sat1 + (y + 1) * stride + xa + 1;
+      double* row2 = sat2 + (y + 1) * stride + xa + 1;
+      double a1[kSatRowSeg], a2[kSatRowSeg];
+#pragma unroll
+      for (int i = 0; i < kSatRowSeg; ++i) { a1[i] = row1[i < last ? i : last]; a2[i] = row2[i < last ? i : last]; }
+#pragma unroll
+      for (int i = 0; i < kSatRowSeg; ++i) { row1[i < last ? i : last] = a1[i] + o1[k]; row2[i < last ? i : last] = a2[i] + o2[k]; }
+    }
+  }
+  __syncthreads();
+  SPR_PSTAMP(7);
+  // ---- columns 1..w of both tables: unit (table, stretch, column), consecutive work-items on consecutive columns ----
+  const int units = 2 * kSatSeg * w;
+  constexpr int B = 8;
+  for (int u = tid; u < units; u += nthr) {
+    const int rest = u / w, x = u - rest * w + 1, sg = rest % kSatSeg;
+    const int ya = sg * hseg, n = (ya + hseg < h ? ya + hseg : h) - ya;  // rows ya + 1 .. ya + n of the table
+    double* col = (rest / kSatSeg ? sat2 : sat1) + x + (ya + 1) * stride;
+    double run = 0.0;
+    for (int r0 = 0; r0 < n; r0 += B) {
+      double v[B];
+      double* at[B];  // walks down the column, standing still on its last row (no multiply per element)
+      at[0] = col;
+#pragma unroll
+      for (int k = 1; k < B; ++k) at[k] = at[k - 1] + (r0 + k < n ? stride : 0);
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const double t = *at[k];
+        v[k] = r0 + k < n ? t : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        run += v[k];
+        *at[k] = run;
+      }
+      col = at[B - 1] + stride;
+    }
+  }
+  __syncthreads();
+  double off[4];  // up to four turns (256 work-items, w <= 128)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int u = tid + k * nthr < units ? tid + k * nthr : units - 1;
+    const int rest = u / w, x = u - rest * w + 1, sg = rest % kSatSeg;
+    const double* col = (rest / kSatSeg ? sat2 : sat1) + x;
+    off[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < kSatSeg - 1; ++j) {
+      const int e = (j + 1) * hseg < h ? (j + 1) * hseg : h;
+      const double a = col[e * stride];
+      off[k] += j < sg ? a : 0.0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int u = tid + k * nthr;
+    if (u >= units) continue;
+    const int rest = u / w, x = u - rest * w + 1, sg = rest % kSatSeg;
+    if (sg == 0) continue;
+    const int ya = sg * hseg, n = (ya + hseg < h ? ya + hseg : h) - ya;
+    double* col = (rest / kSatSeg ? sat2 : sat1) + x + (ya + 1) * stride;
+    for (int r0 = 0; r0 < n; r0 += B) {
+      double v[B];
+      double* at[B];
+      at[0] = col;
+#pragma unroll
+      for (int i = 1; i < B; ++i) at[i] = at[i - 1] + (r0 + i < n ? stride : 0);
+#pragma unroll
+      for (int i = 0; i < B; ++i) v[i] = *at[i];
+#pragma unroll
+      for (int i = 0; i < B; ++i) *at[i] = v[i] + off[k];
+      col = at[B - 1] + stride;
+    }
+  }
+  __syncthreads();
+}
+
 // 1/sigma from the two window sums: var = S2 - S1^2/(th*tw) in float64 (that is where the cancellation is),
 // var <= 0 -> 0 (similarity.py:65, :70); the reciprocal square root of the positive result only needs float32
 // accuracy (hardware v_rsq_f32, ~1 ulp: relative error ~2e-7).
@@ -190,7 +348,11 @@ __device__ __forceinline__ void inv_sigma_map_fused(const float* x0, int h, int 
                                                     double* sat2, Store store) {
   const int tid = static_cast<int>(threadIdx.x);
   const int n = h * w;
-  build_sat_pair(x0, h, w, sat1, sat2);
+  if (sat_blocked_fits(h, w))
+    build_sat_pair_blocked(x0, h, w, sat1, sat2);
+  else
+    build_sat_pair(x0, h, w, sat1, sat2);
+  SPR_PSTAMP(8);
   const double inv_n = 1.0 / (static_cast<double>(th) * static_cast<double>(tw));
   const int stride = w + 1;
   const int dy = wg_size() / w, dx = wg_size() - dy * w;

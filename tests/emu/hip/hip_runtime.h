@@ -128,9 +128,13 @@ inline void run_block(BlockCtx& b, dim3 block) {
     makecontext(&f.ctx, reinterpret_cast<void (*)()>(fiber_main), 2, static_cast<unsigned>(p & 0xffffffffu),
                 static_cast<unsigned>(p >> 32));
   }
+  // SPR_EMU_ORDER=reverse runs the work-items of a sweep from the last to the first: results that depend on which
+  // work-item gets to an address first (a data race the ascending order happens to resolve the right way) change
+  static const bool reverse = [] { const char* e = std::getenv("SPR_EMU_ORDER"); return e && e[0] == 'r'; }();
   for (;;) {
     bool ran = false, all_done = true;
-    for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < n; ++k) {
+      const int i = reverse ? n - 1 - k : k;
       Fiber& f = b.fibers[i];
       if (f.state == RUN) {
         b.cur = i;

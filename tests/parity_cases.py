@@ -97,6 +97,18 @@ BIG_SHAPE_CASES = [(3, 128, 64, 128, 64), (2, 100, 70, 100, 70), (2, 90, 50, 120
                    (2, 128, 64, 130, 60), (2, 97, 41, 110, 52)]
 
 
+def check_narrow_maps(scorer):
+    """Full correlation maps of narrow and short images (stretches of the blocked table scans that are empty or ragged:
+    a width of 6 leaves the fourth column stretch empty) against the oracle - every pixel, not only the maximum."""
+    rng = np.random.default_rng(11)
+    for (th, tw), (ih, iw) in [((8, 6), (8, 6)), ((5, 3), (5, 3)), ((4, 6), (9, 7)), ((7, 2), (11, 5)), ((3, 3), (6, 17))]:
+        t = rng.random((th, tw), dtype=np.float32)
+        i = rng.random((ih, iw), dtype=np.float32)
+        got = similarity.normxcorr(t, i, "same", scorer=scorer)
+        want = oracle.normxcorr(t, i, precise=True)
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=0, err_msg=f"{th}x{tw} on {ih}x{iw}")
+
+
 def check_shape_case(scorer, case, tol=TIGHT):
     c, qh, qw, gh, gw = case
     same = (qh, qw) == (gh, gw)

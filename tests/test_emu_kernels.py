@@ -37,6 +37,25 @@ def test_emu_golden_get_similarity(scorer):
     pc.check_golden_get_similarity(scorer, max_elems=64 * 32 * 16)
 
 
+def test_emu_narrow_maps(scorer):
+    pc.check_narrow_maps(scorer)
+
+
+def test_emu_reverse_work_item_order():
+    """The emulation runs the work-items of a workgroup one after another, in ascending order, so a data race between
+    work-items always resolves the same way - possibly the right way, where the hardware does not (round 2: two work-items
+    of one wave storing to the same table entry).  SPR_EMU_ORDER=reverse runs them in descending order: the checks that
+    compare whole maps and matrices must not notice."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SPR_EMU_ORDER="reverse")
+    sel = "narrow_maps or golden_normxcorr or golden_ragged or accumulate or matrix_core or sparse_channels"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k", sel],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", pc.SHAPE_CASES)
 def test_emu_shape_classes(scorer, case):
     pc.check_shape_case(scorer, case)

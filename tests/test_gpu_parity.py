@@ -52,6 +52,10 @@ def test_golden_normxcorr(scorer):
     pc.check_golden_normxcorr(scorer)
 
 
+def test_narrow_maps(scorer):
+    pc.check_narrow_maps(scorer)
+
+
 def test_golden_get_similarity_all_sizes(scorer):
     # includes the 512x64x32 (conv4_3) and 256x128x64 (conv3_3) stacks
     pc.check_golden_get_similarity(scorer, max_elems=1 << 40)
