@@ -21,6 +21,12 @@
 
 #include "ncc_prep_common.h"
 
+// -DSPR_MFMA_ABL=n: timing ablations (wrong results), tools/ubench/ablate_mfma.sh.  1: no epilogues, 2: one fragment read per
+// period instead of one per step, 3: no staging of the next channel, 4: no reloads of the template fragments
+#ifndef SPR_MFMA_ABL
+#define SPR_MFMA_ABL 0
+#endif
+
 namespace spr {
 
 namespace {
@@ -32,11 +38,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     f(std::integral_constant<int, I>{});
     static_for<I + 1, N>(f);
   }
-}
-
-constexpr int round_to_residue(int v, int modulus, int residue) {
-  int r = v - v % modulus + residue;
-  return r < v ? r + modulus : r;
 }
 
 template <int TH_, int TW_>
@@ -52,16 +53,22 @@ struct MCfg {
   static constexpr int PR = 2 * TH - 1;  // rows of the zero-padded map
   static constexpr int CY = TH / 2, CX = TW / 2;
   static_assert(NPOS % 16 == 0 && TH % 2 == 0 && NTILE % TP == 0 && DY % 2 == 0 && TW <= 16, "unsupported map size");
-  // LDS image of one channel: copy k (0..7) holds P shifted left by k elements, in chunks of 8 elements (16 bytes):
-  // chunk (copy k, chunk column jj, row r) at (k>>2)*CSG + (k&3)*16 + jj*JS + r*64; the residues of JS and CSG modulo
-  // 256 make the sixteen lanes of a fragment read hit sixteen different 16-byte bank groups.
-  static constexpr int JS = round_to_residue(PR * 64, 256, 128);
-  static constexpr int CSG = round_to_residue(3 * JS, 256, 192);
-  static constexpr int HL = 2 * CSG;  // lo plane behind the hi plane
+  // LDS image of one channel: copy k (0..7) holds P shifted left by k elements, in chunks of 8 elements (16 bytes): chunk
+  // (copy k, chunk column jj, row r) at jj * JS + r * RS + k * 16 - the eight copies of a row side by side (128 bytes), JS a
+  // multiple of the 256-byte bank row.  ds_read_b128 is served in four groups of sixteen lanes that are NOT contiguous
+  // ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS): of the layouts with a linear chunk -> bank-slot map this is the best,
+  // 16 LDS cycles for the twelve (phase, group) reads of a fragment step against 12 without conflicts and 24 for the
+  // first layout of this kernel (measured there: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).
+  static constexpr int RS = 128;
+  static constexpr int JS = (PR + 1) / 2 * 2 * RS;
+  static constexpr int HL = 3 * JS;  // lo plane behind the hi plane
   static constexpr int kCopyBytes = 2 * HL;
   static constexpr int kEbOff = kCopyBytes;                // float b[NPOS], (b*S1)[NPOS]
-  static constexpr int kBufBytes = kEbOff + 2 * 4 * NPOS;  // one channel; two buffers: channel c + 1 is staged under channel c
-  static constexpr int kLdsBytes = 2 * kBufBytes;
+  static constexpr int kDummyOff = kEbOff + 2 * 4 * NPOS;  // 16 bytes nobody reads: where masked-out stores go (no branches)
+  static constexpr int kBufBytes = kDummyOff + 16;         // one channel; three buffers: channels c - 1 and c are read while
+  static constexpr int kLdsBytes = 3 * kBufBytes;          // channel c + 1 is staged
+  static constexpr int PERIOD = 2 * KS;                    // row offsets (even) one channel takes per tile group
+  static_assert(DY * (NTG - 1) < PERIOD, "a tile group may lag the first one by less than a channel");
   static_assert(kBufBytes % 16 == 0, "buffer alignment");
   // prepared layouts
   static constexpr int kQMapBytes = TH * 16 * 2;           // per channel: template rows padded to 16 taps (bf16)
@@ -124,7 +131,10 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
       const unsigned lo = bf16_round(v - bf16_value(hi));
       hl[i] = (hi << 16) | lo;
     }
-    build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
+    if (sat_blocked_fits(M::TH, M::TW))
+      build_sat_pair_blocked(x0, M::TH, M::TW, sat1, sat2);
+    else
+      build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
     const double inv_n = 1.0 / static_cast<double>(M::NPOS);
     for (int i = tid; i < M::NPOS; i += kThreads) {
       const int y = i / M::TW, x = i - y * M::TW;
@@ -169,32 +179,37 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
   // low half: byte offset of the pixel in copy 0 (row, column); high half: its column in the padded map
   auto pixel_base = [&](int e) {
     const int iy = e / M::TW, ix = e - iy * M::TW;
-    return ((iy + M::CY) * 64 + 2 * (ix + M::CX)) | ((ix + M::CX) << 16);
+    return ((iy + M::CY) * M::RS + 2 * (ix + M::CX)) | ((ix + M::CX) << 16);
   };
   const int pb0 = pixel_base(tid), pb1 = pixel_base(e1);
-  auto stage_store_pixel = [&](unsigned char* buf, int pb, unsigned hl) {
-    const int w = pb >> 16, rowb = pb & 0xffff;
-    const uint16_t hi = static_cast<uint16_t>(hl >> 16), lo = static_cast<uint16_t>(hl & 0xffffu);
+  // Branch-free on purpose: the channel loop below must stay ONE basic block, or the compiler sinks the epilogues of the
+  // fragment steps before a branch into the block behind it, where they run with the matrix cores idle.  A copy that does
+  // not hold the pixel stores to the buffer's dummy slot; a work-item without a second pixel stores its first one twice.
+  // part k of 8: both pixels of this work-item into copy k (part 0 also the two epilogue weights); the parts go to different
+  // fragment steps of the period - one burst of all 32 + 4 stores per wave holds up the fragment reads of all four waves
+  auto stage_store_part = [&](unsigned char* buf, auto k_c) {
+    constexpr int k = decltype(k_c)::value;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int e = 0; e < 2; ++e) {
+      const int pb = e ? pb1 : pb0;
+      const unsigned hl = st_hl[e];
+      const int w = pb >> 16, rowb = pb & 0xffff;
       const int mm = w - k;  // column of the pixel in copy k
-      if (k <= M::CX || mm >= 0) {  // w >= CX: only the far copies can push the first columns out
-        const int addr = (k >> 2) * M::CSG + (k & 3) * 16 - 2 * k + rowb + (M::JS - 16) * (mm >> 3);
-        *reinterpret_cast<uint16_t*>(buf + addr) = hi;
-        *reinterpret_cast<uint16_t*>(buf + addr + M::HL) = lo;
-      }
+      const int addr = k * 16 - 2 * k + rowb + (M::JS - 16) * (mm >> 3);
+      const bool held = k <= M::CX || mm >= 0;  // w >= CX: only the far copies can push the first columns out
+      *reinterpret_cast<uint16_t*>(buf + (held ? addr : M::kDummyOff)) = static_cast<uint16_t>(hl >> 16);
+      *reinterpret_cast<uint16_t*>(buf + (held ? addr + M::HL : M::kDummyOff + 2)) = static_cast<uint16_t>(hl & 0xffffu);
     }
-  };
-  auto stage_store = [&](unsigned char* buf) {
-    float* eb = reinterpret_cast<float*>(buf + M::kEbOff);
-    stage_store_pixel(buf, pb0, st_hl[0]);
-    eb[tid] = st_b[0];
-    eb[M::NPOS + tid] = st_bs[0];
-    if (has1) {
-      stage_store_pixel(buf, pb1, st_hl[1]);
+    if constexpr (k == 0) {
+      float* eb = reinterpret_cast<float*>(buf + M::kEbOff);
+      eb[tid] = st_b[0];
+      eb[M::NPOS + tid] = st_bs[0];
       eb[e1] = st_b[1];
       eb[M::NPOS + e1] = st_bs[1];
     }
+  };
+  auto stage_store = [&](unsigned char* buf) {
+    static_for<0, 8>([&](auto k_c) { stage_store_part(buf, k_c); });
   };
 
   // ---- query side --------------------------------------------------------------------------------------------------
@@ -215,101 +230,172 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
   for (int ph = 0; ph < M::TP; ++ph) {
     const int p = 16 * ph + col, y = p / M::TW, x = p - y * M::TW;
     const int m0 = x + 8 * (kg & 1), k = m0 & 7;
-    frag_base[ph] = (k >> 2) * M::CSG + (k & 3) * 16 + (m0 >> 3) * M::JS + (y + (kg >> 1)) * 64;
+    frag_base[ph] = k * 16 + (m0 >> 3) * M::JS + (y + (kg >> 1)) * M::RS;
   }
 
-  f32x4 run[M::NTILE];
+  // ---- steady-state schedule --------------------------------------------------------------------------------------
+  // Time runs in row offsets tau = PERIOD * c + sigma (sigma = 0, 2, .. PERIOD - 2; three tile phases per step).  Tile group
+  // tg works DY * tg behind the first one: at (c, sigma) it is at d = sigma - DY * tg of channel c if d >= 0, else at
+  // d + PERIOD of channel c - 1 - so every step issues the same 2 * NTG MFMAs per phase, one tile in TP * DY / 2 steps is
+  // finished and weighted, and the ramp-up / ramp-down of a channel-by-channel schedule (where a fragment read feeds one
+  // or two MFMAs and the epilogues bunch at the end) is gone.  Channels c - 1 and c are both read from LDS while c + 1 is
+  // staged (three buffers); the template fragments are double-buffered in registers (two periods unrolled), each reloaded
+  // with channel c + 1 more than a channel before its first use.  The loop runs channels + 1 periods: in the first the
+  // "previous channel" is all zeros (weights 0), in the last the "current" one is read but never weighted.
+  f32x4 run[M::NTILE], acc[M::NTILE];
 #pragma unroll
-  for (int t = 0; t < M::NTILE; ++t) run[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 A[M::KS];
+  for (int t = 0; t < M::NTILE; ++t) { run[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  u32x4 A[2][M::KS];
+  const int last_c = g.channels - 1;
   if (active) {
 #pragma unroll
-    for (int ks = 0; ks < M::KS; ++ks) A[ks] = load_a(0, ks);
+    for (int ks = 0; ks < M::KS; ++ks) {
+      A[0][ks] = load_a(0, ks);
+      A[1][ks] = u32x4{0u, 0u, 0u, 0u};
+    }
+    // (the first PERIOD - DY * (NTG - 1) offsets of a channel are done with before the previous period ends)
+#pragma unroll
+    for (int ks = 0; ks < (M::PERIOD - M::DY * (M::NTG - 1)) / 2; ++ks) A[1][ks] = load_a(last_c < 1 ? last_c : 1, ks);
   }
   stage_load(0);
   __syncthreads();  // the zero fill is complete
   stage_store(lds);
-  stage_load(g.channels > 1 ? 1 : 0);
+  stage_load(last_c < 1 ? last_c : 1);
   __syncthreads();
 
-  constexpr int NIT = (M::SMAX / 2 + 1) * M::TP;
-  constexpr int IT_STAGE = NIT / 3;  // where the next channel's image is written (its global loads are a third of a channel old)
-  for (int c = 0; c < g.channels; ++c) {
-    unsigned char* buf = lds + (c & 1) * M::kBufBytes;
-    unsigned char* buf_next = lds + ((c + 1) & 1) * M::kBufBytes;
-    const int cn = c + 1 < g.channels ? c + 1 : c;
-    const int cnn = c + 2 < g.channels ? c + 2 : c;
-    if (active) {
-      const float* eb = reinterpret_cast<const float*>(buf + M::kEbOff);
-      f32x2 sc[4];  // {a, a * mean} of this lane's four queries
+  constexpr int NIT = M::KS * M::TP;       // fragment steps per period
+  constexpr int IT_STAGE = 4, kStageEvery = 2;  // channel c + 1 is written to LDS in eight parts, every other step from here
+  static_assert(IT_STAGE + 7 * kStageEvery < NIT, "staging must end inside the period");
+  f32x2 sc_cur[4], sc_prev[4];             // {a, a * mean} of this lane's four queries, channels c and c - 1
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sc[r] = buf_ld8(q_rs, sc_off[r], static_cast<unsigned>(c) * 8u);
-      auto load_frag = [&](int ph, int s, int plane) {
-        return *reinterpret_cast<const u32x4*>(buf + frag_base[ph] + s * 64 + plane * M::HL);
+  for (int r = 0; r < 4; ++r) sc_cur[r] = f32x2{0.f, 0.f};
+  float ebv = 0.f, ebsv = 0.f;             // 1/sigma and S1/sigma of the tile whose epilogue is due
+  int b_prev = 2 * M::kBufBytes, b_cur = 0, b_next = M::kBufBytes;  // byte offsets of the three channel buffers
+
+  auto period = [&](auto par_c, int c) {
+    constexpr int PAR = decltype(par_c)::value;
+    unsigned char* buf_cur = lds + b_cur;
+    unsigned char* buf_prev = lds + b_prev;
+    unsigned char* buf_next = lds + b_next;
+    const int c1 = c + 1 < g.channels ? c + 1 : last_c, c2 = c + 2 < g.channels ? c + 2 : last_c;
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc_prev[r] = sc_cur[r];
+        const f32x2 v = buf_ld8(q_rs, sc_off[r], static_cast<unsigned>(c < g.channels ? c : last_c) * 8u);
+        sc_cur[r] = c < g.channels ? v : f32x2{0.f, 0.f};
+      }
+      const float* eb_cur = reinterpret_cast<const float*>(buf_cur + M::kEbOff);
+      const float* eb_prev = reinterpret_cast<const float*>(buf_prev + M::kEbOff);
+      auto load_frag = [&](const unsigned char* buf, int ph, int s, int plane) {
+        return *reinterpret_cast<const u32x4*>(buf + frag_base[ph] + s * M::RS + plane * M::HL);
       };
-      f32x4 acc[M::NTILE];
-      auto epilogue = [&](int t) {
-        const float bt = eb[16 * t + col], bst = eb[M::NPOS + 16 * t + col];
+      // tile finished by fragment step `it` of a period: group 0 finishes the CURRENT channel in the last sigma step, group
+      // tg > 0 the PREVIOUS channel at sigma = DY * tg - 2.  -1: none
+      auto finished = [](int it) constexpr {
+        const int sg = 2 * (it / M::TP), ph = it % M::TP;
+        if (sg == M::PERIOD - 2) return ph;
+        if ((sg + 2) % M::DY == 0 && (sg + 2) / M::DY >= 1 && (sg + 2) / M::DY < M::NTG) return ((sg + 2) / M::DY) * M::TP + ph;
+        return -1;
+      };
+      auto epilogue = [&](int t, bool of_prev, int chan) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = bt * acc[t][r];
-          run[t][r] = fmaf(-sc[r].y, bst, fmaf(sc[r].x, v, run[t][r]));
+          const f32x2 w = of_prev ? sc_prev[r] : sc_cur[r];
+          const float v = ebv * acc[t][r];
+          run[t][r] = fmaf(-w.y, ebsv, fmaf(w.x, v, run[t][r]));
           if constexpr (MAPS) {  // spr_ncc_maps: the channel's own map of the first query
-            if (r == 0 && wave == 0 && kg == 0)
-              maps_out[static_cast<size_t>(c) * M::NPOS + 16 * t + col] = fmaf(-sc[r].y, bst, sc[r].x * v);
+            if (r == 0 && wave == 0 && kg == 0 && chan >= 0 && chan < g.channels)
+              maps_out[static_cast<size_t>(chan) * M::NPOS + 16 * t + col] = fmaf(-w.y, ebsv, w.x * v);
           }
         }
       };
-      // fragment ring: the reads of fragment it + kAhead are issued before the MFMAs of fragment it (the scheduling fences
-      // keep them there: left alone, the compiler sinks every read to just in front of its first use)
-      constexpr int kAhead = 4, kRing = 5;
-      u32x4 bh[kRing], bl[kRing];
-      static_for<0, kAhead>([&](auto j_c) {
+      // fragment ring: the reads of step it + kAhead are issued before the MFMAs of step it (the scheduling fences keep
+      // them there: left alone, the compiler sinks every read to just in front of its first use)
+      constexpr int kAhead = 2, kRing = 3;
+      u32x4 fch[kRing], fcl[kRing], fph[kRing], fpl[kRing];
+      auto issue = [&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
-        bh[j] = load_frag(j % M::TP, 2 * (j / M::TP), 0);
-        bl[j] = load_frag(j % M::TP, 2 * (j / M::TP), 1);
-      });
+        constexpr int sg = 2 * (j / M::TP), ph = j % M::TP, slot = j % kRing;
+        fch[slot] = load_frag(buf_cur, ph, sg, 0);
+        fcl[slot] = load_frag(buf_cur, ph, sg, 1);
+        if constexpr (sg + M::PERIOD <= M::SMAX) {
+          fph[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 0);
+          fpl[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 1);
+        }
+      };
+      static_for<0, kAhead>(issue);
       static_for<0, NIT>([&](auto it_c) {
         constexpr int it = decltype(it_c)::value;
-        constexpr int s = 2 * (it / M::TP), ph = it % M::TP, slot = it % kRing;
-        if constexpr (it + kAhead < NIT) {
-          constexpr int s1 = 2 * ((it + kAhead) / M::TP), ph1 = (it + kAhead) % M::TP;
-          bh[(it + kAhead) % kRing] = load_frag(ph1, s1, 0);
-          bl[(it + kAhead) % kRing] = load_frag(ph1, s1, 1);
+        constexpr int sg = 2 * (it / M::TP), ph = it % M::TP, slot = it % kRing;
+        if constexpr (it + kAhead < NIT && (SPR_MFMA_ABL != 2 || it + kAhead < kRing)) issue(std::integral_constant<int, it + kAhead>{});
+        // the tile finished by the previous step (its MFMAs have had time to drain) is weighted and added now; the two
+        // weights of the tile this step finishes are requested for the next
+        constexpr int tdone = finished((it + NIT - 1) % NIT);
+        float eb_now = ebv, ebs_now = ebsv;
+        (void)eb_now; (void)ebs_now;
+        constexpr int tnext = finished(it);
+        float nb = 0.f, nbs = 0.f;
+        if constexpr (tnext >= 0) {
+          const float* e = tnext < M::TP ? eb_cur : eb_prev;
+          nb = e[16 * tnext + col];
+          nbs = e[M::NPOS + 16 * tnext + col];
         }
         sched_fence();
-        if constexpr (it > 0) {  // the tile finished by the previous fragment (its MFMAs have had time to drain)
-          constexpr int sp = 2 * ((it - 1) / M::TP), php = (it - 1) % M::TP;
-          constexpr int d = sp - 2 * (M::KS - 1);
-          if constexpr (d >= 0 && d % M::DY == 0 && d / M::DY < M::NTG) epilogue((d / M::DY) * M::TP + php);
+        if constexpr (tdone >= 0 && SPR_MFMA_ABL != 1) {
+          // (group 0's last tile is finished by the last step of the PREVIOUS period: by now it belongs to channel c - 1)
+          constexpr bool cur_chan = tdone < M::TP && it != 0;
+          epilogue(tdone, !cur_chan, cur_chan ? c : c - 1);
         }
-        if constexpr (it == IT_STAGE) {
-          stage_store(buf_next);
-          stage_load(cnn);
+        if constexpr (tnext >= 0) { ebv = nb; ebsv = nbs; }
+        if constexpr (SPR_MFMA_ABL != 3 && it >= IT_STAGE && it < IT_STAGE + 8 * kStageEvery && (it - IT_STAGE) % kStageEvery == 0) {
+          stage_store_part(buf_next, std::integral_constant<int, (it - IT_STAGE) / kStageEvery>{});
+          if constexpr (it == IT_STAGE + 7 * kStageEvery) stage_load(c2);
         }
         static_for<0, M::NTG>([&](auto tg_c) {
           constexpr int tg = decltype(tg_c)::value;
-          constexpr int k2 = s - M::DY * tg;
-          if constexpr (k2 >= 0 && k2 < 2 * M::KS) {
-            constexpr int ks = k2 / 2, t = tg * M::TP + ph;
+          constexpr int d = sg - M::DY * tg;
+          constexpr int t = tg * M::TP + ph;
+          if constexpr (d >= 0) {
+            constexpr int ks = d / 2;
             if constexpr (ks == 0)
-              acc[t] = mfma_bf16_16x16x32(A[ks], bh[slot], f32x4{0.f, 0.f, 0.f, 0.f});
+              acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fch[slot], f32x4{0.f, 0.f, 0.f, 0.f});
             else
-              acc[t] = mfma_bf16_16x16x32(A[ks], bh[slot], acc[t]);
-            acc[t] = mfma_bf16_16x16x32(A[ks], bl[slot], acc[t]);
-            // the last use of this template row pair in the channel: fetch the next channel's into the same registers
-            if constexpr (tg == M::NTG - 1 && ph == M::TP - 1) A[ks] = load_a(cn, ks);
+              acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fch[slot], acc[t]);
+            acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fcl[slot], acc[t]);
+          } else {
+            constexpr int ks = (d + M::PERIOD) / 2;
+            acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fph[slot], acc[t]);
+            acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fpl[slot], acc[t]);
           }
         });
+        // template row pairs nobody needs any more: the previous channel's (the slowest group has just used it) is
+        // replaced by channel c + 1's, and at the end of the period the first ones of this channel by channel c + 2's
+        if constexpr (ph == M::TP - 1 && SPR_MFMA_ABL != 4) {
+          constexpr int lag = M::DY * (M::NTG - 1);
+          if constexpr (sg + M::PERIOD - lag < M::PERIOD) {
+            constexpr int ks = (sg + M::PERIOD - lag) / 2;
+            A[PAR ^ 1][ks] = load_a(c1, ks);
+          } else {
+            constexpr int ks = (sg - lag) / 2;
+            A[PAR][ks] = load_a(c2, ks);
+          }
+        }
         sched_fence();
       });
-      epilogue((M::NTG - 1) * M::TP + M::TP - 1);
     } else {
       stage_store(buf_next);
-      stage_load(cnn);
+      stage_load(c2);
     }
-    __syncthreads();  // channel c + 1 is staged; nobody reads channel c's image any more
+    __syncthreads();  // channel c + 1 is staged; nobody reads channel c - 1's image any more
+    const int t0 = b_prev;
+    b_prev = b_cur; b_cur = b_next; b_next = t0;
+  };
+  for (int c = 0; c <= g.channels; c += 2) {
+    period(std::integral_constant<int, 0>{}, c);
+    if (c + 1 <= g.channels) period(std::integral_constant<int, 1>{}, c + 1);
   }
+  // group 0's last tile of the last period is still to be weighted - with weight 0 (it belongs to "channel" channels)
 
   if (!active || !scores) return;  // spr_ncc_maps passes no score matrix
   // spatial maximum per query: over this lane's tiles, then over the sixteen lanes holding the other positions

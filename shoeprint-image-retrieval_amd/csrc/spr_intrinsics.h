@@ -44,6 +44,10 @@ __device__ __forceinline__ int opaque(int v) {
 // The instruction scheduler may not move anything across this point (software-pipelined loops: keeps LDS reads
 // issued where the source issues them, ahead of the arithmetic that is meant to hide them).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Ordering request to the scheduler inside one fenced region: the next group holds up to SIZE instructions of the kinds in
+// MASK (0x8 MFMA, 0x2 VALU, 0x4 SALU, 0x20 VMEM read, 0x100 LDS read, 0x200 LDS write); groups are laid down in call order.
+template <int MASK, int SIZE>
+__device__ __forceinline__ void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, SIZE, 0); }
 
 // Pin a value in its vector registers at this point of the program (the compiler may not move its computation below).
 __device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }

@@ -43,6 +43,8 @@ inline int opaque(int v) { return v; }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 inline void pin(f32x2&) {}
 inline void sched_fence() {}
+template <int MASK, int SIZE>
+inline void sched_group() {}
 
 // soft team barrier: workgroups run one after another here, so the wait is the timeout case (returns at once)
 inline void team_arrive(unsigned* counter, unsigned n) { __atomic_fetch_add(counter, n, __ATOMIC_RELAXED); }

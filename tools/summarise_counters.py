@@ -19,7 +19,7 @@ def main():
             n[k][r["Counter_Name"]].add(r["Dispatch_Id"])
     out = {}
     for k in acc:
-        if not any(s in k for s in ("pair6", "pair_fft", "prep_fft", "conv_mfma", "conv_first")):
+        if not any(s in k for s in ("pair6", "pair_fft", "pair_mfma", "prep_fft", "prep_mfma", "conv_mfma", "conv_first")):
             continue
         c = {name: acc[k][name] / len(n[k][name]) for name in acc[k]}
         derived = {}
