@@ -439,16 +439,18 @@ def main(argv=None):
         launches = len(pair_events)
         if plan0.method == 4:
             # matrix-core direct form (ncc_mfma.hip): priced against the dense bf16 MFMA peak on the ALGORITHMIC flops of the
-            # sliding-window form, 2 * taps * positions per pair and channel; the kernel issues 2.67x that (template rows padded
-            # 12 -> 16 taps, the centred search map entering as hi + lo), which the fraction below therefore counts as loss
+            # sliding-window form, 2 * taps * positions per pair and channel; the kernel issues 1.33x that (template rows padded
+            # 12 -> 16 taps; 2.67x in the hi + lo form), which the fraction below therefore counts as loss; the time is that of
+            # the score call: pair kernels and, in the exact form, the f32 correction-matrix kernels between them
             taps = ih * iw
             flops_pair = 2.0 * taps * taps * c0
             achieved = flops_pair * pair_pairs / (pair_ms * 1e-3) / 1e12
-            issued = 2.0 * (ih * 16) * taps * 2 * c0
+            exact = plans[0].gallery_item_bytes > c0 * 4032 + 4096  # the exact form's prepared items carry a V matrix
+            issued = 2.0 * (ih * 16) * taps * (1 if exact else 2) * c0
             bytes_pair = c0 * h0 * w0 * 2
             hbm = bytes_pair * pair_pairs / (pair_ms * 1e-3) / 1e9
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pair_mfma_kernel",
+                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pair_mfma_kernel" + (" + corr_mfma_kernel (exact form)" if exact else " (hi + lo form)"),
                         "launches": launches, "avg_launch_ms": round(pair_ms / launches, 3),
                         "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 4),
                         "issued_mfma_gflop_per_pair": round(issued / 1e9, 4),

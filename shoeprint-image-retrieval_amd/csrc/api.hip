@@ -71,6 +71,7 @@ struct spr_ncc_plan {
   unsigned* team_sync = nullptr;  // device: arrival counters of the pair kernel's 8 workgroup teams
   spr::FftWorkspace ws{nullptr, 0, nullptr};  // device: scratch of the "big" geometries (maps beyond LDS)
   float* six_ctab = nullptr;  // device: pre-twist table of the six-wave pair kernel
+  float* mfma_x = nullptr;    // device: correction matrix of the matrix-core method's exact form (one call at a time per plan)
 };
 
 using namespace spr;
@@ -134,7 +135,8 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   const bool fft_ok = fft_geometry(gf, shape->method == SPR_NCC_FFT_POW2), direct_ok = direct_geometry(gd);
   // SPR_NCC_MFMA=0 in the environment keeps SPR_NCC_AUTO off the matrix-core kernel (A/B runs)
   const char* mfma_env = std::getenv("SPR_NCC_MFMA");
-  const bool mfma_ok = mfma_geometry(g), mfma_auto = mfma_ok && !(mfma_env && mfma_env[0] == '0');
+  NccGeom gm = g;
+  const bool mfma_ok = mfma_geometry(gm), mfma_auto = mfma_ok && !(mfma_env && mfma_env[0] == '0');
   if (shape->method == SPR_NCC_MFMA) {
     if (!mfma_ok) { set_error("matrix-core method: bfloat16 maps of 28x12 (cropped) on both sides only, got dtype %d, query %dx%d vs gallery %dx%d", g.dtype, g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
     method = SPR_NCC_MFMA;
@@ -157,7 +159,13 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   spr_ncc_plan* p = new (std::nothrow) spr_ncc_plan();
   if (!p) { set_error("out of host memory"); return SPR_ERR_ARG; }
   p->method = method;
-  p->geom = method == SPR_NCC_FFT ? gf : method == SPR_NCC_MFMA ? g : gd;
+  p->geom = method == SPR_NCC_FFT ? gf : method == SPR_NCC_MFMA ? gm : gd;
+  if (method == SPR_NCC_MFMA && mfma_workspace_bytes(p->geom) > 0 &&
+      hipMalloc(reinterpret_cast<void**>(&p->mfma_x), mfma_workspace_bytes(p->geom)) != hipSuccess) {
+    set_error("hipMalloc(%zu bytes of correction matrix) failed", mfma_workspace_bytes(p->geom));
+    spr_ncc_plan_destroy(p);
+    return SPR_ERR_WORKSPACE;
+  }
   if (method == SPR_NCC_FFT) {
     int rc = make_twiddles(p->geom.nh, &p->tw_h);
     if (rc == SPR_OK) rc = make_twiddles(p->geom.nw, &p->tw_w);
@@ -202,6 +210,7 @@ extern "C" void spr_ncc_plan_destroy(spr_ncc_plan* plan) {
   if (plan->team_sync) (void)hipFree(plan->team_sync);
   if (plan->ws.base) (void)hipFree(plan->ws.base);
   if (plan->six_ctab) (void)hipFree(plan->six_ctab);
+  if (plan->mfma_x) (void)hipFree(plan->mfma_x);
   delete plan;
 }
 
@@ -257,7 +266,7 @@ extern "C" int spr_ncc_score(spr_ncc_plan* plan, const void* pq, int64_t nq, con
     return launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
                            plan->tw_w, plan->team_sync, plan->ws, s);
   if (plan->method == SPR_NCC_MFMA)
-    return launch_pair_mfma(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
+    return launch_pair_mfma(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->mfma_x, s);
   return launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
 }
 
@@ -267,6 +276,6 @@ extern "C" int spr_ncc_maps(spr_ncc_plan* plan, const void* pq, const void* pg, 
   if (plan->method == SPR_NCC_FFT)
     return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w,
                            plan->geom.big ? plan->team_sync : nullptr, plan->ws, s);
-  if (plan->method == SPR_NCC_MFMA) return launch_pair_mfma(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
+  if (plan->method == SPR_NCC_MFMA) return launch_pair_mfma(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->mfma_x, s);
   return launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
 }

@@ -4,19 +4,25 @@
 //
 // Per channel the numerator of similarity.py:48-55 is a product of a [queries x taps] with a [taps x positions] matrix:
 //     num[q, p] = sum_tap t0[q, tap] * I0z[p + tap]        (I0z = centred search map, zero outside: scipy 'same')
-//               = sum_tap t[q, tap] * I0z[p + tap] - mean(t[q]) * S1[p]         (S1 = window sum of I0z, :59)
-// A = the RAW template values: bfloat16 as stored, so every product below is exact.  B = I0z, which is not a bfloat16
-// number after centring: it enters as hi + lo (two bfloat16 numbers, 16 significant bits) and costs two MFMAs.
+// A = the RAW template values: bfloat16 as stored, so every product below is exact.  Two forms of B:
+//   exact (default): B = the RAW search map, zero outside - one MFMA per tile step, products exact on both sides - and
+//       num = R - mean(I) * St0[q,p] - mean(t) * SI[p]   (St0: the centred template summed over the taps that fall inside
+//       the map at p; SI: window sum of the raw map).  The last term is a weight of the epilogue; the middle one, summed
+//       over the channels with the weights, is a [queries x channels] x [channels x gallery] product PER POSITION:
+//       corr_mfma_kernel (f32 matrix cores, 0.6 % of the flops) writes it before the pair kernel subtracts it at the end.
+//   split (SPR_NCC_MFMA_EXACT=0): B = I0z = hi + lo, two bfloat16 numbers (16 significant bits), two MFMAs per tile step,
+//       num = R - mean(t) * S1[p]  (S1 = window sum of I0z, :59); self-contained, half as fast.
 // B is never materialised: it is a Toeplitz gather from the zero-padded map of the channel, kept in LDS in eight copies
 // shifted by one element each so that every lane's eight consecutive taps are one aligned ds_read_b128.
 // A fragment (8 taps of 16 positions) depends on (row of the position + row of the tap) only, so one fragment read
 // feeds up to NTG tiles of 16 positions, each against another template row pair: 78 fragment reads for 294 tile steps.
 //
 // One workgroup = one gallery item x 64 queries (one wave = 16 queries = the M side of v_mfma_f32_16x16x32_bf16), walking
-// the channels: per channel 2 x 294 MFMAs per wave, then per position  sum += a[q] * (b[p] * acc) - (a*mean)[q] * (b*S1)[p]
+// the channels: per channel 294 (split: 588) MFMAs per wave, then per position  sum += a[q] * (b[p] * acc) - (a*mean)[q] * (b*S)[p]
 // (a = 1/sqrt(sum t0^2), b = 1/sigma of the window, both float32 from float64 statistics as in the other methods),
 // channel sum in registers, spatial maximum and the running maximum over variants at the end (similarity.py:100-108,
 // :355-367).
+#include <cstdlib>
 #include <type_traits>
 
 #include "ncc_prep_common.h"
@@ -73,13 +79,19 @@ struct MCfg {
   // prepared layouts
   static constexpr int kQMapBytes = TH * 16 * 2;           // per channel: template rows padded to 16 taps (bf16)
   static constexpr int kGChanBytes = 3 * 4 * NPOS;         // per channel: b, b*S1 (float), hi|lo (one word per pixel)
+  // exact form: U[position][channel] (query) and V[position][channel] (gallery) follow, channels padded to 16 (zeros)
+  static constexpr int kXQ = 64;                           // queries per block = row length of the correction matrix
 };
+__host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 
 struct MfmaArgs {
   int channels, nq, ng;
   long long ld, col0;
   int accumulate;
   unsigned q_item_bytes, g_item_bytes;
+  // exact form: x[position][gallery item of this launch][query of the block] = sum_c U V, subtracted from the channel sums
+  const float* x;
+  int x_items;
 };
 
 __device__ __forceinline__ unsigned bf16_round(float v) {  // round to nearest even, finite inputs
@@ -89,7 +101,13 @@ __device__ __forceinline__ unsigned bf16_round(float v) {  // round to nearest e
 __device__ __forceinline__ float bf16_value(unsigned bits) { return __uint_as_float(bits << 16); }
 
 // ---- preparation: grid = (channels, items) ---------------------------------------------------------------------------
-template <class M>
+// EXACT form: the search map enters the matrix cores RAW (bf16 as stored: one MFMA per tile step, every product exact) and
+// the centring of both sides becomes two corrections of the raw product R[q,p] = sum_tap t[q,tap] Iz[p + tap]:
+//     num = R - mean(I) * St0[q,p] - mean(t) * SI[p],     St0 = sum of the centred template over the taps whose pixel lies
+//                                                          inside the map at position p, SI = window sum of the raw map
+// The last term is a weight of the pair kernel's epilogue like before (b * SI in place of b * S1); the middle one is a
+// contraction over the channels per position, X[q,g,p] = sum_c (a St0)[q,c,p] * (b mean(I))[g,c,p], left to corr_mfma_kernel.
+template <class M, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                  size_t item_bytes) {
@@ -101,7 +119,21 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
   const int c = static_cast<int>(blockIdx.x);
   const size_t item = blockIdx.y;
   const int tid = static_cast<int>(threadIdx.x);
+  const int cp = pad16(g.channels);
   unsigned char* out_item = prepared + item * item_bytes;
+  const uint16_t* raw = static_cast<const uint16_t*>(maps);
+  auto build_tables = [&]() {
+    if (sat_blocked_fits(M::TH, M::TW))
+      build_sat_pair_blocked(x0, M::TH, M::TW, sat1, sat2);
+    else
+      build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
+  };
+  // the channel columns that pad U / V to a multiple of 16 are zero: the last channel's workgroup writes them
+  auto store_column = [&](float* mat, int pos, float v) {
+    mat[static_cast<size_t>(pos) * cp + c] = v;
+    if (c == g.channels - 1)
+      for (int k = g.channels; k < cp; ++k) mat[static_cast<size_t>(pos) * cp + k] = 0.0f;
+  };
   if (is_query) {
     const size_t base = (item * g.channels + c) * static_cast<size_t>(g.q_h) * g.q_w;
     float mean;
@@ -109,46 +141,157 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
     const float scale = template_scale(x0, M::NPOS, red);
     // template rows as stored (bfloat16 bit patterns), padded to 16 taps
     uint16_t* rows = reinterpret_cast<uint16_t*>(out_item + static_cast<size_t>(c) * M::kQMapBytes);
-    const uint16_t* raw = static_cast<const uint16_t*>(maps);
-    for (int i = tid; i < M::TH * 16; i += kThreads) {
+    for (int i = tid; i < M::TH * 16; i += wg_size()) {
       const int u = i >> 4, v = i & 15;
       rows[i] = v < M::TW ? raw[base + static_cast<size_t>(u + g.crop) * g.q_w + (v + g.crop)] : static_cast<uint16_t>(0);
     }
+    float* sc = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kQMapBytes);
     if (tid == 0) {
-      float* sc = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kQMapBytes) + 2 * c;
-      sc[0] = scale;
-      sc[1] = scale * mean;
+      sc[2 * c] = scale;
+      sc[2 * c + 1] = scale * mean;
+    }
+    if constexpr (EXACT) {
+      float* U = sc + 2 * g.channels;
+      build_tables();
+      const int stride = M::TW + 1;
+      for (int i = tid; i < M::NPOS; i += wg_size()) {
+        const int y = i / M::TW, x = i - y * M::TW;
+        // taps (u, v) whose pixel (y + u - CY, x + v - CX) lies inside the map
+        const int u0 = M::CY - y > 0 ? M::CY - y : 0, u1 = M::CY - y + M::TH < M::TH ? M::CY - y + M::TH : M::TH;
+        const int v0 = M::CX - x > 0 ? M::CX - x : 0, v1 = M::CX - x + M::TW < M::TW ? M::CX - x + M::TW : M::TW;
+        const double st0 = sat1[u1 * stride + v1] - sat1[u0 * stride + v1] - sat1[u1 * stride + v0] + sat1[u0 * stride + v0];
+        store_column(U, i, scale * static_cast<float>(st0));
+      }
     }
   } else {
     const size_t base = (item * g.channels + c) * static_cast<size_t>(g.g_h) * g.g_w;
-    load_centred(maps, base, g.g_w, g.crop, M::TH, M::TW, g.dtype, x0, red);
+    float mean;
+    load_centred(maps, base, g.g_w, g.crop, M::TH, M::TW, g.dtype, x0, red, &mean);
     float* eb = reinterpret_cast<float*>(out_item + static_cast<size_t>(c) * M::kGChanBytes);
     float* ebs = eb + M::NPOS;
     unsigned* hl = reinterpret_cast<unsigned*>(ebs + M::NPOS);
-    for (int i = tid; i < M::NPOS; i += kThreads) {
-      const float v = x0[i];
-      const unsigned hi = bf16_round(v);
-      const unsigned lo = bf16_round(v - bf16_value(hi));
-      hl[i] = (hi << 16) | lo;
+    for (int i = tid; i < M::NPOS; i += wg_size()) {
+      if constexpr (EXACT) {
+        const int y = i / M::TW, x = i - y * M::TW;
+        hl[i] = static_cast<unsigned>(raw[base + static_cast<size_t>(y + g.crop) * g.g_w + (x + g.crop)]) << 16;
+      } else {
+        const float v = x0[i];
+        const unsigned hi = bf16_round(v);
+        const unsigned lo = bf16_round(v - bf16_value(hi));
+        hl[i] = (hi << 16) | lo;
+      }
     }
-    if (sat_blocked_fits(M::TH, M::TW))
-      build_sat_pair_blocked(x0, M::TH, M::TW, sat1, sat2);
-    else
-      build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
+    build_tables();
+    if constexpr (EXACT) {  // the mean of the channel, behind V: vcol_mfma_kernel turns b and the means into V[position][channel]
+      float* means = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kGChanBytes) +
+                     static_cast<size_t>(M::NPOS) * cp;
+      if (tid == 0) means[c] = mean;
+    }
     const double inv_n = 1.0 / static_cast<double>(M::NPOS);
-    for (int i = tid; i < M::NPOS; i += kThreads) {
+    for (int i = tid; i < M::NPOS; i += wg_size()) {
       const int y = i / M::TW, x = i - y * M::TW;
       const double s1 = window_sum(sat1, M::TH, M::TW, M::TH, M::TW, y, x);
       const double s2 = window_sum(sat2, M::TH, M::TW, M::TH, M::TW, y, x);
       const float inv = inv_sigma_from_sums(s1, s2, inv_n);
       eb[i] = inv;
-      ebs[i] = inv * static_cast<float>(s1);
+      if constexpr (EXACT) {
+        const int y0 = y - M::CY > 0 ? y - M::CY : 0, y1 = y - M::CY + M::TH < M::TH ? y - M::CY + M::TH : M::TH;
+        const int xa = x - M::CX > 0 ? x - M::CX : 0, xb = x - M::CX + M::TW < M::TW ? x - M::CX + M::TW : M::TW;
+        const double si = s1 + static_cast<double>(mean) * static_cast<double>((y1 - y0) * (xb - xa));  // window sum of the raw map
+        ebs[i] = inv * static_cast<float>(si);
+      } else {
+        ebs[i] = inv * static_cast<float>(s1);
+      }
     }
   }
 }
 
+// ---- exact form: V[p][c] = b[c][p] * mean[c] of one gallery item, 32 channels per workgroup through an LDS tile (the prep
+// workgroups own one channel each: written from there, V would be 4-byte stores 4 KB apart).  grid = (channel blocks, items)
+template <class M>
+__global__ void __launch_bounds__(kThreads)
+vcol_mfma_kernel(int channels, unsigned char* __restrict__ prepared, size_t item_bytes) {
+  __shared__ float tile[32][M::NPOS + 1];
+  const int tid = static_cast<int>(threadIdx.x);
+  const int cp = pad16(channels), c0 = static_cast<int>(blockIdx.x) * 32;
+  unsigned char* item = prepared + static_cast<size_t>(blockIdx.y) * item_bytes;
+  float* V = reinterpret_cast<float*>(item + static_cast<size_t>(channels) * M::kGChanBytes);
+  const float* means = V + static_cast<size_t>(M::NPOS) * cp;
+  const int p1 = tid + kThreads < M::NPOS ? tid + kThreads : tid;  // second pixel of this work-item (or the first again)
+  for (int cb = 0; cb < 32; cb += 8) {
+    float v0[8], v1[8];  // eight channel rows in flight
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + cb + k < channels ? c0 + cb + k : channels - 1;
+      const float* b = reinterpret_cast<const float*>(item + static_cast<size_t>(c) * M::kGChanBytes);
+      const float m = c0 + cb + k < channels ? means[c] : 0.0f;
+      v0[k] = b[tid] * m;
+      v1[k] = b[p1] * m;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tile[cb + k][tid] = v0[k];
+      tile[cb + k][p1] = v1[k];
+    }
+  }
+  __syncthreads();
+  const int cc = tid & 31;
+  if (c0 + cc < cp)
+    for (int p = tid >> 5; p < M::NPOS; p += kThreads / 32) V[static_cast<size_t>(p) * cp + c0 + cc] = tile[cc][p];
+}
+
+// ---- exact form: X[p][g][q] = sum_c U[q][p][c] * V[g][p][c] on the f32 matrix cores (exact f32 products) ---------------
+// grid = (blocks of 64 gallery items, positions); a wave = 16 queries x 64 gallery items, K = channels in steps of 16.
+template <class M>
+__global__ void __launch_bounds__(kThreads)
+corr_mfma_kernel(int channels, int nq_here, int ng, const unsigned char* __restrict__ q_block, unsigned q_item_bytes,
+                 unsigned u_off, const unsigned char* __restrict__ pg, unsigned g_item_bytes, unsigned v_off,
+                 float* __restrict__ x, int x_items) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int lane = tid & 63, wave = tid >> 6, i16 = lane & 15, kgrp = lane >> 4;
+  const int cp = pad16(channels);
+  const int p = static_cast<int>(blockIdx.y);
+  const int g0 = static_cast<int>(blockIdx.x) * 64;
+  const int q = wave * 16 + i16 < nq_here ? wave * 16 + i16 : nq_here - 1;
+  const float* up = reinterpret_cast<const float*>(q_block + static_cast<size_t>(q) * q_item_bytes + u_off) +
+                    static_cast<size_t>(p) * cp + 4 * kgrp;
+  const float* vp[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int gi = g0 + 16 * nt + i16 < ng ? g0 + 16 * nt + i16 : ng - 1;
+    vp[nt] = reinterpret_cast<const float*>(pg + static_cast<size_t>(gi) * g_item_bytes + v_off) + static_cast<size_t>(p) * cp +
+             4 * kgrp;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < cp; c0 += 16) {
+    const float4 a = *reinterpret_cast<const float4*>(up + c0);
+    float4 b[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const float4*>(vp[nt] + c0);
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float bv = m == 0 ? b[nt].x : m == 1 ? b[nt].y : m == 2 ? b[nt].z : b[nt].w;
+        acc[nt] = mfma_f32_16x16x4(av[m], bv, acc[nt]);
+      }
+    }
+  }
+  // lane owns rows (queries) 4 * kgrp .. + 3 of its wave's sixteen, column (gallery item) i16 of every tile
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int gl = g0 + 16 * nt + i16;
+    if (gl < ng)
+      *reinterpret_cast<float4*>(x + (static_cast<size_t>(p) * x_items + gl) * M::kXQ + wave * 16 + 4 * kgrp) =
+          float4{acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
+  }
+}
+
 // ---- pair kernel: grid = (gallery items, blocks of 64 queries) ---------------------------------------------------------
-template <class M, bool MAPS>
+template <class M, bool MAPS, bool EXACT>
 __global__ void __launch_bounds__(kThreads, 1)
 pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigned char* __restrict__ pg,
                  float* __restrict__ scores, float* __restrict__ maps_out) {
@@ -198,7 +341,8 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
       const int addr = k * 16 - 2 * k + rowb + (M::JS - 16) * (mm >> 3);
       const bool held = k <= M::CX || mm >= 0;  // w >= CX: only the far copies can push the first columns out
       *reinterpret_cast<uint16_t*>(buf + (held ? addr : M::kDummyOff)) = static_cast<uint16_t>(hl >> 16);
-      *reinterpret_cast<uint16_t*>(buf + (held ? addr + M::HL : M::kDummyOff + 2)) = static_cast<uint16_t>(hl & 0xffffu);
+      if constexpr (!EXACT)
+        *reinterpret_cast<uint16_t*>(buf + (held ? addr + M::HL : M::kDummyOff + 2)) = static_cast<uint16_t>(hl & 0xffffu);
     }
     if constexpr (k == 0) {
       float* eb = reinterpret_cast<float*>(buf + M::kEbOff);
@@ -305,8 +449,16 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
           const float v = ebv * acc[t][r];
           run[t][r] = fmaf(-w.y, ebsv, fmaf(w.x, v, run[t][r]));
           if constexpr (MAPS) {  // spr_ncc_maps: the channel's own map of the first query
-            if (r == 0 && wave == 0 && kg == 0 && chan >= 0 && chan < g.channels)
-              maps_out[static_cast<size_t>(chan) * M::NPOS + 16 * t + col] = fmaf(-w.y, ebsv, w.x * v);
+            if (r == 0 && wave == 0 && kg == 0 && chan >= 0 && chan < g.channels) {
+              float m = fmaf(-w.y, ebsv, w.x * v);
+              if constexpr (EXACT) {  // this channel's term of the contraction, for the one pair of spr_ncc_maps
+                const int cp = pad16(g.channels), pos = 16 * t + col;
+                const float* U = reinterpret_cast<const float*>(q_block + static_cast<size_t>(g.channels) * (M::kQMapBytes + 8));
+                const float* V = reinterpret_cast<const float*>(g_item + static_cast<size_t>(g.channels) * M::kGChanBytes);
+                m -= U[static_cast<size_t>(pos) * cp + chan] * V[static_cast<size_t>(pos) * cp + chan];
+              }
+              maps_out[static_cast<size_t>(chan) * M::NPOS + 16 * t + col] = m;
+            }
           }
         }
       };
@@ -318,10 +470,10 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
         constexpr int j = decltype(j_c)::value;
         constexpr int sg = 2 * (j / M::TP), ph = j % M::TP, slot = j % kRing;
         fch[slot] = load_frag(buf_cur, ph, sg, 0);
-        fcl[slot] = load_frag(buf_cur, ph, sg, 1);
+        if constexpr (!EXACT) fcl[slot] = load_frag(buf_cur, ph, sg, 1);
         if constexpr (sg + M::PERIOD <= M::SMAX) {
           fph[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 0);
-          fpl[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 1);
+          if constexpr (!EXACT) fpl[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 1);
         }
       };
       static_for<0, kAhead>(issue);
@@ -362,11 +514,11 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
               acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fch[slot], f32x4{0.f, 0.f, 0.f, 0.f});
             else
               acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fch[slot], acc[t]);
-            acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fcl[slot], acc[t]);
+            if constexpr (!EXACT) acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fcl[slot], acc[t]);
           } else {
             constexpr int ks = (d + M::PERIOD) / 2;
             acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fph[slot], acc[t]);
-            acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fpl[slot], acc[t]);
+            if constexpr (!EXACT) acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fpl[slot], acc[t]);
           }
         });
         // template row pairs nobody needs any more: the previous channel's (the slowest group has just used it) is
@@ -399,6 +551,14 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
 
   if (!active || !scores) return;  // spr_ncc_maps passes no score matrix
   // spatial maximum per query: over this lane's tiles, then over the sixteen lanes holding the other positions
+  if constexpr (EXACT) {
+#pragma unroll
+    for (int t = 0; t < M::NTILE; ++t) {
+      const float4 xv = *reinterpret_cast<const float4*>(g.x + (static_cast<size_t>(16 * t + col) * g.x_items + gi) * M::kXQ +
+                                                         wave * 16 + 4 * kg);
+      run[t][0] -= xv.x; run[t][1] -= xv.y; run[t][2] -= xv.z; run[t][3] -= xv.w;
+    }
+  }
   float best[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -429,17 +589,29 @@ bool mfma_shape_ok(const NccGeom& g) {
 
 }  // namespace
 
-bool mfma_geometry(const NccGeom& g) {
+constexpr int kCorrItems = 1024;  // gallery items per launch of the exact form = what the plan's correction matrix holds
+
+bool mfma_geometry(NccGeom& g) {
   if (!mfma_shape_ok(g)) return false;
+  // SPR_NCC_MFMA_EXACT=0: the centred search map as hi + lo (two MFMAs per tile step, no correction matrix)
+  const char* e = std::getenv("SPR_NCC_MFMA_EXACT");
+  g.mfma_exact = !(e && e[0] == '0');
   // buffer-load offsets of a 64-query block and the scalar channel offsets are 32-bit
-  return static_cast<size_t>(g.channels) * (M2812::kQMapBytes + 8) * 64 < (static_cast<size_t>(1) << 31);
+  return mfma_query_item_bytes(g) * 64 < (static_cast<size_t>(1) << 31);
 }
 
 size_t mfma_query_item_bytes(const NccGeom& g) {
-  return align_up(static_cast<size_t>(g.channels) * (M2812::kQMapBytes + 8), 256);
+  size_t b = static_cast<size_t>(g.channels) * (M2812::kQMapBytes + 8);
+  if (g.mfma_exact) b += sizeof(float) * M2812::NPOS * static_cast<size_t>(pad16(g.channels));
+  return align_up(b, 256);
 }
 size_t mfma_gallery_item_bytes(const NccGeom& g) {
-  return align_up(static_cast<size_t>(g.channels) * M2812::kGChanBytes, 256);
+  size_t b = static_cast<size_t>(g.channels) * M2812::kGChanBytes;
+  if (g.mfma_exact) b += sizeof(float) * (M2812::NPOS + 1) * static_cast<size_t>(pad16(g.channels));  // V, then the means
+  return align_up(b, 256);
+}
+size_t mfma_workspace_bytes(const NccGeom& g) {
+  return g.mfma_exact ? sizeof(float) * M2812::NPOS * static_cast<size_t>(kCorrItems) * M2812::kXQ : 0;
 }
 
 int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream) {
@@ -447,34 +619,77 @@ int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t 
   using M = M2812;
   const size_t lds = align_up(64 + sizeof(float) * M::NPOS, 16) + 2 * sizeof(double) * (M::TH + 1) * (M::TW + 1);
   const size_t item_bytes = is_query ? mfma_query_item_bytes(g) : mfma_gallery_item_bytes(g);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(prep_mfma_kernel<M>), dim3(g.channels, static_cast<unsigned>(n)), dim3(kThreads), lds,
-                     stream, g, is_query ? 1 : 0, maps, static_cast<unsigned char*>(prepared), item_bytes);
-  return check_launch("prep_mfma_kernel");
+  auto kernel = g.mfma_exact ? prep_mfma_kernel<M, true> : prep_mfma_kernel<M, false>;
+  // one wave per (item, channel): maps of 336 pixels leave a 256-lane workgroup waiting at its ~20 barriers
+  hipLaunchKernelGGL(kernel, dim3(g.channels, static_cast<unsigned>(n)), dim3(64), lds, stream, g, is_query ? 1 : 0, maps,
+                     static_cast<unsigned char*>(prepared), item_bytes);
+  int rc = check_launch("prep_mfma_kernel");
+  if (rc == SPR_OK && g.mfma_exact && !is_query) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(vcol_mfma_kernel<M>), dim3((pad16(g.channels) + 31) / 32, static_cast<unsigned>(n)),
+                       dim3(kThreads), 0, stream, g.channels, static_cast<unsigned char*>(prepared), item_bytes);
+    rc = check_launch("vcol_mfma_kernel");
+  }
+  return rc;
+}
+
+template <bool EXACT>
+static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
+                              int64_t ld, int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream) {
+  using M = M2812;
+  auto kernel = maps_out ? pair_mfma_kernel<M, true, EXACT> : pair_mfma_kernel<M, false, EXACT>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+  const size_t q_item = mfma_query_item_bytes(g), g_item = mfma_gallery_item_bytes(g);
+  const unsigned char* pqb = static_cast<const unsigned char*>(pq);
+  const unsigned char* pgb = static_cast<const unsigned char*>(pg);
+  if (!EXACT || maps_out) {
+    const unsigned q_blocks = static_cast<unsigned>((nq + 63) / 64);
+    // HIP refuses a grid of 2^32 work-items or more: slices of the gallery
+    int64_t max_g = pair_tiles_per_launch(1, kThreads) / q_blocks;
+    if (max_g < 1) max_g = 1;
+    for (int64_t g0 = 0; g0 < ng; g0 += max_g) {
+      const int64_t n = ng - g0 < max_g ? ng - g0 : max_g;
+      MfmaArgs a{g.channels, static_cast<int>(nq), static_cast<int>(n), static_cast<long long>(ld),
+                 static_cast<long long>(col0 + g0), accumulate, static_cast<unsigned>(q_item), static_cast<unsigned>(g_item),
+                 nullptr, 0};
+      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n), q_blocks), dim3(kThreads), M::kLdsBytes, stream, a, pqb,
+                         pgb + static_cast<size_t>(g0) * g_item, scores, maps_out);
+      const int rc = check_launch("pair_mfma_kernel");
+      if (rc != SPR_OK) return rc;
+    }
+    return SPR_OK;
+  }
+  // exact form: per block of 64 queries and slice of the gallery, the correction matrix first, then the pairs
+  if (!xws) { set_error("pair_mfma_kernel: the exact form needs the plan's correction matrix"); return SPR_ERR_ARG; }
+  int64_t max_g = pair_tiles_per_launch(1, kThreads);
+  if (max_g > kCorrItems) max_g = kCorrItems;
+  const unsigned u_off = static_cast<unsigned>(static_cast<size_t>(g.channels) * (M::kQMapBytes + 8));
+  const unsigned v_off = static_cast<unsigned>(static_cast<size_t>(g.channels) * M::kGChanBytes);
+  for (int64_t q0 = 0; q0 < nq; q0 += 64) {
+    const int nq_here = static_cast<int>(nq - q0 < 64 ? nq - q0 : 64);
+    for (int64_t g0 = 0; g0 < ng; g0 += max_g) {
+      const int n = static_cast<int>(ng - g0 < max_g ? ng - g0 : max_g);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(corr_mfma_kernel<M>), dim3((n + 63) / 64, M::NPOS), dim3(kThreads), 0, stream,
+                         g.channels, nq_here, n, pqb + static_cast<size_t>(q0) * q_item, static_cast<unsigned>(q_item), u_off,
+                         pgb + static_cast<size_t>(g0) * g_item, static_cast<unsigned>(g_item), v_off, xws, n);
+      int rc = check_launch("corr_mfma_kernel");
+      if (rc != SPR_OK) return rc;
+      MfmaArgs a{g.channels, nq_here, n, static_cast<long long>(ld), static_cast<long long>(col0 + g0), accumulate,
+                 static_cast<unsigned>(q_item), static_cast<unsigned>(g_item), xws, n};
+      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n), 1), dim3(kThreads), M::kLdsBytes, stream, a,
+                         pqb + static_cast<size_t>(q0) * q_item, pgb + static_cast<size_t>(g0) * g_item,
+                         scores ? scores + static_cast<size_t>(q0) * ld : nullptr, maps_out);
+      rc = check_launch("pair_mfma_kernel");
+      if (rc != SPR_OK) return rc;
+    }
+  }
+  return SPR_OK;
 }
 
 int launch_pair_mfma(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
-                     int64_t col0, int accumulate, float* maps_out, hipStream_t stream) {
+                     int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream) {
   if (nq == 0 || ng == 0) return SPR_OK;
-  using M = M2812;
-  auto kernel = maps_out ? pair_mfma_kernel<M, true> : pair_mfma_kernel<M, false>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  const unsigned q_blocks = static_cast<unsigned>((nq + 63) / 64);
-  const size_t g_item = mfma_gallery_item_bytes(g);
-  // HIP refuses a grid of 2^32 work-items or more: slices of the gallery
-  int64_t max_g = pair_tiles_per_launch(1, kThreads) / q_blocks;
-  if (max_g < 1) max_g = 1;
-  for (int64_t g0 = 0; g0 < ng; g0 += max_g) {
-    const int64_t n = ng - g0 < max_g ? ng - g0 : max_g;
-    MfmaArgs a{g.channels, static_cast<int>(nq), static_cast<int>(n), static_cast<long long>(ld),
-               static_cast<long long>(col0 + g0), accumulate, static_cast<unsigned>(mfma_query_item_bytes(g)),
-               static_cast<unsigned>(g_item)};
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n), q_blocks), dim3(kThreads),
-                       M::kLdsBytes, stream, a, static_cast<const unsigned char*>(pq),
-                       static_cast<const unsigned char*>(pg) + static_cast<size_t>(g0) * g_item, scores, maps_out);
-    const int rc = check_launch("pair_mfma_kernel");
-    if (rc != SPR_OK) return rc;
-  }
-  return SPR_OK;
+  return g.mfma_exact ? launch_pair_mfma_t<true>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream)
+                      : launch_pair_mfma_t<false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
 }
 
 }  // namespace spr

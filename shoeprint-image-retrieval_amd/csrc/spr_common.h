@@ -55,6 +55,8 @@ struct NccGeom {
   int pad_h, pad_w;    // zero-padded search map: ih+th-1, iw+tw-1
   int strips_per_row;  // strips of kStrip output pixels per output row
   int strips_per_thread;
+  // matrix-core method only -----------------------------------------------------------------
+  int mfma_exact;      // 1: raw search map on the matrix cores + correction matrix (ncc_mfma.hip), 0: hi + lo
 };
 
 constexpr int kStrip = 8;  // output pixels per register strip in the direct kernel
@@ -88,12 +90,13 @@ int launch_pair_fft(const NccGeom& g, const void* pq, int64_t nq, const void* pg
                     unsigned* team_sync, const FftWorkspace& ws,
                     hipStream_t stream);  // team_sync: 8 x 32 counters, or null (tile mode only)
 // direct form on the bf16 matrix cores (ncc_mfma.hip): small maps stored as bfloat16
-bool mfma_geometry(const NccGeom& g);  // true if an instantiated kernel covers this plan
+bool mfma_geometry(NccGeom& g);  // true if an instantiated kernel covers this plan (fills mfma_exact)
 size_t mfma_query_item_bytes(const NccGeom& g);
 size_t mfma_gallery_item_bytes(const NccGeom& g);
+size_t mfma_workspace_bytes(const NccGeom& g);  // the plan's correction matrix of the exact form (0: none)
 int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream);
 int launch_pair_mfma(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
-                     int64_t col0, int accumulate, float* maps_out, hipStream_t stream);
+                     int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream);
 bool fft_geometry(NccGeom& g, bool pow2_only);  // fills the FFT fields; false if no instantiated kernel fits
 bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps do not fit LDS
 

@@ -172,9 +172,15 @@ def test_emu_reduced_precision_configs():
     pc.check_config5_multi_layer_fp16(sc, channels=(2, 4, 4))
 
 
-@pytest.mark.parametrize("channels,nq,ng", [(3, 5, 2), (2, 70, 2), (2, 17, 3)])
+@pytest.mark.parametrize("channels,nq,ng", [(3, 5, 2), (2, 70, 2), (2, 17, 3), (17, 3, 2)])
 def test_emu_matrix_core_method(channels, nq, ng):
     pc.check_mfma_method(emu_scorer, channels, nq, ng)
+
+
+def test_emu_matrix_core_method_split_form(monkeypatch):
+    """SPR_NCC_MFMA_EXACT=0: the centred search map as hi + lo on the matrix cores instead of the raw map + correction matrix."""
+    monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")
+    pc.check_mfma_method(emu_scorer, 3, 20, 2)
 
 
 # ------------------------------------------------------------------------- real library: ABI only

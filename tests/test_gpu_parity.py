@@ -90,10 +90,15 @@ def test_matrix_core_method(lib, channels, nq, ng):
     pc.check_mfma_method(_make_scorer(lib), channels, nq, ng)
 
 
+def test_matrix_core_method_split_form(lib, monkeypatch):
+    monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")
+    pc.check_mfma_method(_make_scorer(lib), 256, 70, 3)
+
+
 def test_matrix_core_method_large_gallery(lib, monkeypatch):
-    """G = 1 000 at the full ResNet50-layer3 shape [1024,32,16] bfloat16 (BASELINE config 3 in shape): the matrix-core form
+    """G = 1 100 (beyond one slice of the correction matrix) at the full ResNet50-layer3 shape [1024,32,16] bfloat16 (BASELINE config 3 in shape): the matrix-core form
     against the FFT form on every pair, against the oracle on sampled pairs, identical ranks, launches sliced."""
-    pc.check_mfma_large_gallery(_make_scorer(lib), monkeypatch, channels=1024, nq=8, ng=1000)
+    pc.check_mfma_large_gallery(_make_scorer(lib), monkeypatch, channels=1024, nq=8, ng=1100)
 
 
 def test_config5_multi_layer_fp16(fft_scorer):
