@@ -587,12 +587,20 @@ def main(argv=None):
             from oracle import ncc_oracle as oracle
 
             gpu_ranks = np.array([oracle.rank_true_match(block[i], cpu["local_match"][i]) for i in range(cpu["sq"])])
-            order_equal = all(np.array_equal(np.argsort(-block[i], kind="stable"), np.argsort(-cpu["matrix"][i], kind="stable"))
-                              for i in range(cpu["sq"]))
+            order_equal, swaps, gap = True, 0, 0.0
+            for i in range(cpu["sq"]):
+                og, oo = np.argsort(-block[i], kind="stable"), np.argsort(-cpu["matrix"][i], kind="stable")
+                diff = np.nonzero(og != oo)[0]
+                if diff.size:  # places where the two orders name different items, and how far apart the ORACLE scores those two
+                    order_equal = False
+                    swaps += int(diff.size)
+                    gap = max(gap, float(np.abs(cpu["matrix"][i][og[diff]] - cpu["matrix"][i][oo[diff]]).max()))
             out["parity_sample"] = {"pairs": int(block.size), "queries": int(cpu["sq"]),
                                     "max_abs_err_vs_oracle": float(f"{err:.3e}"), "tolerance": 1e-4,
                                     "true_match_ranks_equal": bool(np.array_equal(gpu_ranks, cpu["ranks"])),
                                     "full_rank_vectors_equal": bool(order_equal),
+                                    "rank_vector_places_that_differ": swaps,
+                                    "largest_oracle_score_gap_at_such_a_place": float(f"{gap:.3e}"),
                                     "oracle_ranks": [int(r) for r in cpu["ranks"]]}
     if rank == 0:
         print(json.dumps(out))

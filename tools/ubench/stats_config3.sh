@@ -10,6 +10,14 @@ python3 - <<PY
 import csv, glob
 f = glob.glob("$O/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
+import json, re
+out = []
 for r in rows[:8]:
     print(r["Name"][:70], r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 2), "ms total", round(float(r["AverageNs"]) / 1e6, 3), "ms avg")
+    out.append({"kernel": re.split(r"[<(]", re.sub(r"\(anonymous namespace\)::|spr::|void ", "", r["Name"]))[0].strip(),
+                "calls": int(r["Calls"]), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3),
+                "avg_ms": round(float(r["AverageNs"]) / 1e6, 4)})
+json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --config 3 --no-cpu-baseline --no-extractor --steps 2 --warmup 1 "
+                      "(three steps in the trace: one warm-up + two timed)", "kernels": out},
+          open("profiles/r02_config3_kernel_stats.json", "w"), indent=1)
 PY
