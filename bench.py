@@ -214,13 +214,14 @@ def cpu_leg(layer_shape, storage, nq_total, ng_total, target_seconds, cores, sam
 
     sg = sample_g
     if not sg:
-        # size the sample from a calibration pass on these very cores (four pairs per process), not from an assumed rate
-        qs, gal = features(range(min(nq_total, cores)), [0, 1, 2, 3])
+        # size the sample from a calibration pass on these very cores (eight pairs per process), not from an assumed rate;
+        # the short pass still pays more overhead per pair than the long one (it came out 30 % short): allow for that
+        qs, gal = features(range(min(nq_total, cores)), list(range(8)))
         oracle.compare_maps(qs[:1], gal[:1], [0], cfg)  # (pool start-up and imports paid once before the clock runs)
         t0 = time.perf_counter()
         oracle.compare_maps(qs, gal, [0] * len(qs), cfg)
-        rate = len(qs) * 4 / (time.perf_counter() - t0)
-        sg = int(min(ng_total, max(sq, math.ceil(target_seconds * rate / sq))))
+        rate = len(qs) * 8 / (time.perf_counter() - t0)
+        sg = int(min(ng_total, max(sq, math.ceil(1.3 * target_seconds * rate / sq))))
         print(f"[bench] CPU calibration: {rate:.1f} pairs/s on {cores} processes -> sample {sq} x {sg}", file=sys.stderr, flush=True)
     g_ids = sorted({int(matches[q]) for q in range(sq)})
     g_ids += [g for g in range(ng_total) if g not in set(g_ids)][: max(0, sg - len(g_ids))]

@@ -138,7 +138,7 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
   NccGeom gm = g;
   const bool mfma_ok = mfma_geometry(gm), mfma_auto = mfma_ok && !(mfma_env && mfma_env[0] == '0');
   if (shape->method == SPR_NCC_MFMA) {
-    if (!mfma_ok) { set_error("matrix-core method: bfloat16 maps of 28x12 (cropped) on both sides only, got dtype %d, query %dx%d vs gallery %dx%d", g.dtype, g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
+    if (!mfma_ok) { set_error("matrix-core method: bfloat16 / float16 maps of 28x12 (cropped) on both sides only, got dtype %d, query %dx%d vs gallery %dx%d", g.dtype, g.th, g.tw, g.ih, g.iw); return SPR_ERR_UNSUPPORTED; }
     method = SPR_NCC_MFMA;
   } else if (shape->method == SPR_NCC_AUTO && mfma_auto) {
     method = SPR_NCC_MFMA;

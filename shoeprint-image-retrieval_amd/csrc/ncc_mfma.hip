@@ -291,7 +291,7 @@ corr_mfma_kernel(int channels, int nq_here, int ng, const unsigned char* __restr
 }
 
 // ---- pair kernel: grid = (gallery items, blocks of 64 queries) ---------------------------------------------------------
-template <class M, bool MAPS, bool EXACT>
+template <class M, bool MAPS, bool EXACT, bool F16>
 __global__ void __launch_bounds__(kThreads, 1)
 pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigned char* __restrict__ pg,
                  float* __restrict__ scores, float* __restrict__ maps_out) {
@@ -377,6 +377,10 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
     frag_base[ph] = k * 16 + (m0 >> 3) * M::JS + (y + (kg >> 1)) * M::RS;
   }
 
+  auto mfma = [](u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (F16) return mfma_f16_16x16x32(a, b, c);
+    else return mfma_bf16_16x16x32(a, b, c);
+  };
   // ---- steady-state schedule --------------------------------------------------------------------------------------
   // Time runs in row offsets tau = PERIOD * c + sigma (sigma = 0, 2, .. PERIOD - 2; three tile phases per step).  Tile group
   // tg works DY * tg behind the first one: at (c, sigma) it is at d = sigma - DY * tg of channel c if d >= 0, else at
@@ -511,14 +515,14 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
           if constexpr (d >= 0) {
             constexpr int ks = d / 2;
             if constexpr (ks == 0)
-              acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fch[slot], f32x4{0.f, 0.f, 0.f, 0.f});
+              acc[t] = mfma(A[PAR][ks], fch[slot], f32x4{0.f, 0.f, 0.f, 0.f});
             else
-              acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fch[slot], acc[t]);
-            if constexpr (!EXACT) acc[t] = mfma_bf16_16x16x32(A[PAR][ks], fcl[slot], acc[t]);
+              acc[t] = mfma(A[PAR][ks], fch[slot], acc[t]);
+            if constexpr (!EXACT) acc[t] = mfma(A[PAR][ks], fcl[slot], acc[t]);
           } else {
             constexpr int ks = (d + M::PERIOD) / 2;
-            acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fph[slot], acc[t]);
-            if constexpr (!EXACT) acc[t] = mfma_bf16_16x16x32(A[PAR ^ 1][ks], fpl[slot], acc[t]);
+            acc[t] = mfma(A[PAR ^ 1][ks], fph[slot], acc[t]);
+            if constexpr (!EXACT) acc[t] = mfma(A[PAR ^ 1][ks], fpl[slot], acc[t]);
           }
         });
         // template row pairs nobody needs any more: the previous channel's (the slowest group has just used it) is
@@ -584,7 +588,7 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
 using M2812 = MCfg<28, 12>;
 
 bool mfma_shape_ok(const NccGeom& g) {
-  return g.dtype == SPR_BF16 && g.th == M2812::TH && g.tw == M2812::TW && g.ih == M2812::TH && g.iw == M2812::TW;
+  return (g.dtype == SPR_BF16 || g.dtype == SPR_F16) && g.th == M2812::TH && g.tw == M2812::TW && g.ih == M2812::TH && g.iw == M2812::TW;
 }
 
 }  // namespace
@@ -595,7 +599,7 @@ bool mfma_geometry(NccGeom& g) {
   if (!mfma_shape_ok(g)) return false;
   // SPR_NCC_MFMA_EXACT=0: the centred search map as hi + lo (two MFMAs per tile step, no correction matrix)
   const char* e = std::getenv("SPR_NCC_MFMA_EXACT");
-  g.mfma_exact = !(e && e[0] == '0');
+  g.mfma_exact = !(e && e[0] == '0') || g.dtype == SPR_F16;  // half-precision maps: the exact form only (both operands raw)
   // buffer-load offsets of a 64-query block and the scalar channel offsets are 32-bit
   return mfma_query_item_bytes(g) * 64 < (static_cast<size_t>(1) << 31);
 }
@@ -632,11 +636,11 @@ int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t 
   return rc;
 }
 
-template <bool EXACT>
+template <bool EXACT, bool F16>
 static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                               int64_t ld, int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream) {
   using M = M2812;
-  auto kernel = maps_out ? pair_mfma_kernel<M, true, EXACT> : pair_mfma_kernel<M, false, EXACT>;
+  auto kernel = maps_out ? pair_mfma_kernel<M, true, EXACT, F16> : pair_mfma_kernel<M, false, EXACT, F16>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
   const size_t q_item = mfma_query_item_bytes(g), g_item = mfma_gallery_item_bytes(g);
   const unsigned char* pqb = static_cast<const unsigned char*>(pq);
@@ -688,8 +692,9 @@ static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, cons
 int launch_pair_mfma(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
                      int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream) {
   if (nq == 0 || ng == 0) return SPR_OK;
-  return g.mfma_exact ? launch_pair_mfma_t<true>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream)
-                      : launch_pair_mfma_t<false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
+  if (g.dtype == SPR_F16) return launch_pair_mfma_t<true, true>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
+  return g.mfma_exact ? launch_pair_mfma_t<true, false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream)
+                      : launch_pair_mfma_t<false, false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
 }
 
 }  // namespace spr

@@ -215,4 +215,10 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// The same with IEEE half-precision operands (products of two halves are exact in f32 as well).
+__device__ __forceinline__ f32x4 mfma_f16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 }  // namespace spr

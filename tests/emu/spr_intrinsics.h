@@ -157,7 +157,12 @@ inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
 
 // bf16 MFMA: every lane publishes its two 16-byte fragments; products of bf16 values are exact in float, the
 // accumulation is a k-ordered float chain (the hardware's internal order is not documented: tests use tolerances)
-inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+template <bool F16>
+inline f32x4 mfma_16bit_16x16x32(u32x4 a, u32x4 b, f32x4 c);
+inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) { return mfma_16bit_16x16x32<false>(a, b, c); }
+inline f32x4 mfma_f16_16x16x32(u32x4 a, u32x4 b, f32x4 c) { return mfma_16bit_16x16x32<true>(a, b, c); }
+template <bool F16>
+inline f32x4 mfma_16bit_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
   hipemu::BlockCtx* blk = hipemu::t_blk;
   const int me = blk->cur, w0 = me & ~(kWave - 1), l = me - w0;
   std::memcpy(&blk->xf[8 * me], &a, 16);
@@ -166,6 +171,11 @@ inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
   auto elem = [&](int lane, int which, int j) {
     uint16_t bits;
     std::memcpy(&bits, reinterpret_cast<const char*>(&blk->xf[8 * (w0 + lane) + 4 * which]) + 2 * j, 2);
+    if (F16) {
+      _Float16 h;
+      std::memcpy(&h, &bits, 2);
+      return static_cast<float>(h);
+    }
     const uint32_t u = static_cast<uint32_t>(bits) << 16;
     float f;
     std::memcpy(&f, &u, 4);

@@ -194,6 +194,20 @@ def check_mfma_method(make_scorer, channels, nq, ng, tol=TIGHT):
         make_scorer("mfma").plan(channels, (32, 16), (32, 16), dtype=np.float32)
 
 
+def check_mfma_method_fp16(make_scorer, channels, nq, ng, tol=TIGHT):
+    """The same kernel on float16-stored maps (VGG16 conv5_3 of BASELINE config 5): v_mfma_f32_16x16x32_f16, exact form."""
+    from shoeprint_image_retrieval_amd import _lib
+
+    g = [np.maximum(synth.gallery_features(53, i, channels, 32, 16), 0).astype(np.float16) for i in range(ng)]
+    q = [np.maximum(synth.query_features(53, i % ng, i, channels, 32, 16), 0).astype(np.float16) for i in range(nq)]
+    sc = make_scorer("auto")
+    dev = sc.dev
+    assert sc.plan(channels, (32, 16), (32, 16), dtype=np.float16).method == _lib.NCC_MFMA
+    got = dev.to_host(sc.scores_device(dev.to_device(np.stack(q)), dev.to_device(np.stack(g))))
+    ref = oracle.similarity_matrix([a.astype(np.float32) for a in q], [a.astype(np.float32) for a in g], precise=True)
+    np.testing.assert_allclose(got, ref, atol=tol, rtol=0)
+
+
 def check_mfma_large_gallery(make_scorer, monkeypatch, channels, nq, ng, oracle_pairs=12):
     qb, gb, qf, gf = _bf16_sets(47, channels, nq, ng)
     mf, ff = make_scorer("mfma"), make_scorer("fft")

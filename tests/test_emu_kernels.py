@@ -177,6 +177,10 @@ def test_emu_matrix_core_method(channels, nq, ng):
     pc.check_mfma_method(emu_scorer, channels, nq, ng)
 
 
+def test_emu_matrix_core_method_fp16():
+    pc.check_mfma_method_fp16(emu_scorer, 3, 18, 2)
+
+
 def test_emu_matrix_core_method_split_form(monkeypatch):
     """SPR_NCC_MFMA_EXACT=0: the centred search map as hi + lo on the matrix cores instead of the raw map + correction matrix."""
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")

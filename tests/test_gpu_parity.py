@@ -90,6 +90,10 @@ def test_matrix_core_method(lib, channels, nq, ng):
     pc.check_mfma_method(_make_scorer(lib), channels, nq, ng)
 
 
+def test_matrix_core_method_fp16(lib):
+    pc.check_mfma_method_fp16(_make_scorer(lib), 512, 70, 4)
+
+
 def test_matrix_core_method_split_form(lib, monkeypatch):
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")
     pc.check_mfma_method(_make_scorer(lib), 256, 70, 3)
