@@ -273,6 +273,31 @@ int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, int64_t n, 
                        int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed, void* workspace,
                        float* out, spr_stream_t stream);
 
+/* ------------------------------------------------------------------ EfficientNetV2 feature extractor
+ * network.py:163-175 (model choice), :185-186 (`list(model.features.children())[:block]`), :60-71 / :74-87 (transforms).
+ * arch: 0 = EfficientNetV2_S, 1 = EfficientNetV2_M (the reference's run.toml default), 2 = EfficientNetV2_L; block in
+ * [1, stages + 1]: the stem and block - 1 stages of torchvision's efficientnet_v2 (the closing 1x1 convolution is not built).
+ * The plan flattens the graph into layers (spr_effnet_op_info: int32[16] = kind {0 convolution, 1 depthwise 3x3, 2 squeeze-
+ * excitation}, cin, cout, cin_p, cout_p, ksize, stride, act {0 none, 2 SiLU}, res, sq, feature index, offsets in floats of
+ * w, b, w2, b2 in the packed buffer, block_end).  The caller folds eval-mode BatchNorm (eps 1e-3) into the convolutions and writes
+ * the packed buffer itself (device, spr_effnet_packed_bytes):
+ *   convolution      w at [cout_p/64][K/16][64][16] with K = tap * cin_p + c (zero where padded), b [cout_p]
+ *   depthwise        w [9][c_p], b [c_p]
+ *   squeeze-excite   w = fc1 [sq][c_p], b = fc1 bias [sq], w2 = fc2 [c_p][sq], b2 = fc2 bias [c_p]
+ * images / mean3 / inv_std3 / out as for spr_vgg16_forward (out: device float32 [n, C, h, w], real channels only). */
+typedef struct spr_effnet_plan spr_effnet_plan;
+int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_plan** plan_out);
+void spr_effnet_plan_destroy(spr_effnet_plan* plan);
+int spr_effnet_num_ops(const spr_effnet_plan* plan);
+int spr_effnet_op_info(const spr_effnet_plan* plan, int32_t i, int32_t* info16);
+int spr_effnet_output_shape(const spr_effnet_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels, int32_t* out_h,
+                            int32_t* out_w);
+size_t spr_effnet_packed_bytes(const spr_effnet_plan* plan);
+size_t spr_effnet_workspace_bytes(const spr_effnet_plan* plan, int64_t n, int32_t in_h, int32_t in_w);
+int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                       int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed, void* workspace,
+                       float* out, spr_stream_t stream);
+
 /* ------------------------------------------------------------------ synthetic data
  * Bench/test support: the device twin of shoeprint_image_retrieval_amd/synth.py (bit-identical
  * float32 values).  out: device float32 [n, C, h, w]. */

@@ -145,7 +145,9 @@ template <int KS, int STRIDE>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin, int cout, const float* __restrict__ wts,
                  const float* __restrict__ bias, const float* __restrict__ res, int relu, int nchw,
-                 float* __restrict__ out) {
+                 float* __restrict__ out, const float* __restrict__ in_scale, int cout_real) {
+  // relu: activation code (0 none, 1 ReLU, 2 SiLU); in_scale: [image][cin] factors on the input (squeeze-excitation), or null;
+  // cout_real: channels of an NCHW result when cout is padded (0: all of them)
   __shared__ __attribute__((aligned(16))) float A[kGM * kGS];
   __shared__ __attribute__((aligned(16))) float B[kGN * kGS];
   constexpr int PAD = KS / 2;
@@ -183,6 +185,10 @@ conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin,
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pm_ok && y >= 0 && y < H && x >= 0 && x < W)
       ra = *reinterpret_cast<const float4*>(in + ((pimg * H + y) * static_cast<size_t>(W) + x) * cin + cc * kGK + sq * 4);
+    if (in_scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(in_scale + pimg * cin + cc * kGK + sq * 4);
+      ra.x *= sc.x; ra.y *= sc.y; ra.z *= sc.z; ra.w *= sc.w;
+    }
     rb = *reinterpret_cast<const float4*>(wbase + static_cast<size_t>(ch) * (kGN * kGK));
   };
   request(0);
@@ -212,16 +218,103 @@ conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin,
     for (int j = 0; j < 4; ++j) {
       const int ch = cb * kGN + j * 16 + p;
       float v = acc[j][r] + bias[ch];
+      if (relu == 2) v = v / (1.0f + expf(-v));  // SiLU, in FRONT of the residual sum (EfficientNet blocks)
       if (res) v += res[static_cast<size_t>(m) * cout + ch];
-      if (relu) v = fmaxf(v, 0.0f);
+      if (relu == 1) v = fmaxf(v, 0.0f);         // ReLU, behind it (ResNet bottlenecks)
       if (nchw) {
+        const int creal = cout_real ? cout_real : cout;
+        if (ch >= creal) continue;
         const int ox = static_cast<int>(m % Wo), oy = static_cast<int>((m / Wo) % Ho);
         const size_t img = static_cast<size_t>(m / (static_cast<long long>(Wo) * Ho));
-        out[((img * cout + ch) * Ho + oy) * static_cast<size_t>(Wo) + ox] = v;
+        out[((img * creal + ch) * Ho + oy) * static_cast<size_t>(Wo) + ox] = v;
       } else {
         out[static_cast<size_t>(m) * cout + ch] = v;
       }
     }
+  }
+}
+
+// ================================================================ EfficientNetV2 (network.py:163-175) building blocks
+// Activations NHWC float32 with the channel count padded to a multiple of 64 (the GEMM tile; padded channels hold zeros:
+// zero weights and biases, SiLU(0) = 0); eval-mode BatchNorm folded into the convolutions by the host.
+
+// uint8 grey [n][H][W] (repeated to 3, network.py:60-71) or RGB [n][H][W][3] -> normalised NHWC with 16 channels (3 + zeros)
+__global__ void __launch_bounds__(kThreads)
+enet_input_kernel(const uint8_t* __restrict__ images, size_t pixels, int in_channels, float m0, float m1, float m2, float s0,
+                  float s1, float s2, float* __restrict__ out) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < pixels;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    float v[3];
+    for (int c = 0; c < 3; ++c) v[c] = static_cast<float>(images[in_channels == 3 ? i * 3 + c : i]) * (1.0f / 255.0f);
+    float4* o = reinterpret_cast<float4*>(out + i * 16);
+    o[0] = float4{(v[0] - m0) * s0, (v[1] - m1) * s1, (v[2] - m2) * s2, 0.0f};
+    o[1] = o[2] = o[3] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// depthwise 3x3, stride 1 or 2, pad 1, + bias + SiLU.  One work-item = four channels of one output pixel.
+// weights [tap][C] (channels contiguous), C a multiple of 64
+__global__ void __launch_bounds__(kThreads)
+enet_dw_kernel(const float* __restrict__ in, int n_img, int H, int W, int C, int stride, const float* __restrict__ wts,
+               const float* __restrict__ bias, float* __restrict__ out) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int c4 = C / 4;
+  const size_t total = static_cast<size_t>(n_img) * Ho * Wo * c4;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % c4) * 4;
+    size_t p = i / c4;
+    const int ox = static_cast<int>(p % Wo); p /= Wo;
+    const int oy = static_cast<int>(p % Ho);
+    const size_t img = p / Ho;
+    float4 acc = *reinterpret_cast<const float4*>(bias + c);
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) {
+        const int y = oy * stride + dy - 1, x = ox * stride + dx - 1;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(in + ((img * H + y) * static_cast<size_t>(W) + x) * C + c);
+        const float4 w = *reinterpret_cast<const float4*>(wts + static_cast<size_t>(dy * 3 + dx) * C + c);
+        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y); acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+      }
+    float4 o;
+    o.x = acc.x / (1.0f + expf(-acc.x)); o.y = acc.y / (1.0f + expf(-acc.y));
+    o.z = acc.z / (1.0f + expf(-acc.z)); o.w = acc.w / (1.0f + expf(-acc.w));
+    *reinterpret_cast<float4*>(out + i * 4) = o;
+  }
+}
+
+// squeeze-excitation, step 1: mean over the pixels.  grid = (C / 64, images)
+__global__ void __launch_bounds__(kThreads)
+enet_pool_kernel(const float* __restrict__ in, int HW, int C, float* __restrict__ pooled) {
+  __shared__ float part[4][64];
+  const int tid = static_cast<int>(threadIdx.x), c = tid & 63, r = tid >> 6;
+  const size_t img = blockIdx.y;
+  const float* base = in + img * static_cast<size_t>(HW) * C + static_cast<size_t>(blockIdx.x) * 64 + c;
+  float s = 0.0f;
+  for (int p = r; p < HW; p += 4) s += base[static_cast<size_t>(p) * C];
+  part[r][c] = s;
+  __syncthreads();
+  if (r == 0) pooled[img * C + blockIdx.x * 64 + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / static_cast<float>(HW);
+}
+
+// step 2: scale[c] = sigmoid(W2 SiLU(W1 pooled + b1) + b2).  grid = images; w1 [sq][C], w2 [C][sq] (C padded, sq real)
+__global__ void __launch_bounds__(kThreads)
+enet_fc_kernel(const float* __restrict__ pooled, int C, int sq, const float* __restrict__ w1, const float* __restrict__ b1,
+               const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ scale) {
+  __shared__ float hid[256];
+  const int tid = static_cast<int>(threadIdx.x);
+  const size_t img = blockIdx.x;
+  const float* pv = pooled + img * C;
+  for (int j = tid; j < sq; j += kThreads) {
+    float s = b1[j];
+    for (int c = 0; c < C; ++c) s = fmaf(w1[static_cast<size_t>(j) * C + c], pv[c], s);
+    hid[j] = s / (1.0f + expf(-s));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    float s = b2[c];
+    for (int j = 0; j < sq; ++j) s = fmaf(w2[static_cast<size_t>(c) * sq + j], hid[j], s);
+    scale[img * C + c] = 1.0f / (1.0f + expf(-s));
   }
 }
 
@@ -344,7 +437,7 @@ static int launch_gemm(const RConv& c, const float* in, int64_t n, int h, int w,
   const long long m = static_cast<long long>(n) * ho * wo;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<KS, STRIDE>), dim3(static_cast<unsigned>((m + kGM - 1) / kGM),
                      static_cast<unsigned>(c.cout / kGN)), dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, c.cin, c.cout,
-                     pk + c.w_off, pk + c.b_off, res, c.relu, nchw, out);
+                     pk + c.w_off, pk + c.b_off, res, c.relu, nchw, out, static_cast<const float*>(nullptr), 0);
   return check_launch("conv_gemm_kernel");
 }
 
@@ -415,6 +508,251 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
     x = y;
     y = old;
     i += down ? 4 : 3;
+  }
+  return SPR_OK;
+}
+
+// ================================================================ EfficientNetV2 truncations (network.py:163-175, :185-186)
+// torchvision's efficientnet_v2_{s,m,l}: features = [stem, stage 1 .. stage N, last conv]; the reference keeps
+// features[:block].  Stages of FusedMBConv (3x3 expansion convolution, 1x1 projection) and MBConv (1x1 expansion, depthwise
+// 3x3, squeeze-excitation, 1x1 projection), SiLU, residual where stride 1 and equal widths; stochastic depth is the identity
+// in eval mode.  Flattened here into a list of layers; the host folds BatchNorm (eps 1e-3) and packs the parameters.
+namespace {
+
+struct EOp {
+  int kind;         // 0 convolution (implicit GEMM), 1 depthwise 3x3, 2 squeeze-excitation
+  int cin, cout;    // real channels (squeeze-excitation: cin = cout = expanded width)
+  int cin_p, cout_p;
+  int ks, stride, act;
+  int res;          // convolution: add the block input behind it
+  int scaled;       // convolution: its input is multiplied by the squeeze-excitation factors
+  int sq;           // squeeze-excitation: hidden width
+  int block_end;    // last layer of a residual block (or of the stem)
+  int feature;      // index of the top-level child of `features` this layer belongs to
+  size_t w_off, b_off, w2_off, b2_off;  // floats into the packed buffer (multiples of 4)
+};
+
+struct EStage { int fused, expand, stride, cin, cout, layers; };
+
+const EStage kV2S[] = {{1, 1, 1, 24, 24, 2}, {1, 4, 2, 24, 48, 4}, {1, 4, 2, 48, 64, 4}, {0, 4, 2, 64, 128, 6},
+                       {0, 6, 1, 128, 160, 9}, {0, 6, 2, 160, 256, 15}};
+const EStage kV2M[] = {{1, 1, 1, 24, 24, 3}, {1, 4, 2, 24, 48, 5}, {1, 4, 2, 48, 80, 5}, {0, 4, 2, 80, 160, 7},
+                       {0, 6, 1, 160, 176, 14}, {0, 6, 2, 176, 304, 18}, {0, 6, 1, 304, 512, 5}};
+const EStage kV2L[] = {{1, 1, 1, 32, 32, 4}, {1, 4, 2, 32, 64, 7}, {1, 4, 2, 64, 96, 7}, {0, 4, 2, 96, 192, 10},
+                       {0, 6, 1, 192, 224, 19}, {0, 6, 2, 224, 384, 25}, {0, 6, 1, 384, 640, 7}};
+
+inline int pad64(int c) { return (c + 63) / 64 * 64; }
+
+}  // namespace
+
+struct spr_effnet_plan {
+  int arch, block;
+  std::vector<EOp> ops;
+  size_t packed_floats;
+  int max_expand_p;  // widest expanded tensor (squeeze-excitation scratch)
+};
+
+extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_plan** plan_out) {
+  if (!plan_out) { set_error("spr_effnet_plan_create: null pointer"); return SPR_ERR_ARG; }
+  *plan_out = nullptr;
+  const EStage* stages = arch == 0 ? kV2S : arch == 1 ? kV2M : arch == 2 ? kV2L : nullptr;
+  const int n_stages = arch == 0 ? 6 : 7;
+  if (!stages) { set_error("spr_effnet_plan_create: arch %d (0 = EfficientNetV2_S, 1 = _M, 2 = _L)", arch); return SPR_ERR_ARG; }
+  if (block < 1 || block > n_stages + 1) {
+    set_error("spr_effnet_plan_create: block %d: features[:block] with block in [1, %d] (the last 1x1 convolution is not built)",
+              block, n_stages + 1);
+    return SPR_ERR_ARG;
+  }
+  spr_effnet_plan* plan = new (std::nothrow) spr_effnet_plan();
+  if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
+  plan->arch = arch; plan->block = block; plan->max_expand_p = 64;
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off += (n + 3) / 4 * 4; return o; };
+  auto conv = [&](int cin, int cout, int ks, int stride, int act, int res, int scaled, int end, int feature, int cin_p) {
+    EOp o{};
+    o.kind = 0; o.cin = cin; o.cout = cout; o.cin_p = cin_p; o.cout_p = pad64(cout); o.ks = ks; o.stride = stride; o.act = act;
+    o.res = res; o.scaled = scaled; o.block_end = end; o.feature = feature;
+    o.w_off = take(static_cast<size_t>(o.cout_p) * o.cin_p * ks * ks);
+    o.b_off = take(o.cout_p);
+    plan->ops.push_back(o);
+  };
+  const int stem_out = stages[0].cin;
+  conv(3, stem_out, 3, 2, 2, 0, 0, 1, 0, 16);
+  for (int st = 0; st < block - 1; ++st) {
+    const EStage& g = stages[st];
+    for (int l = 0; l < g.layers; ++l) {
+      const int cin = l == 0 ? g.cin : g.cout, stride = l == 0 ? g.stride : 1;
+      const int exp = cin * g.expand, res = stride == 1 && cin == g.cout;
+      if (g.fused) {
+        if (g.expand == 1) {
+          conv(cin, g.cout, 3, stride, 2, res, 0, 1, st + 1, pad64(cin));
+        } else {
+          conv(cin, exp, 3, stride, 2, 0, 0, 0, st + 1, pad64(cin));
+          conv(exp, g.cout, 1, 1, 0, res, 0, 1, st + 1, pad64(exp));
+        }
+      } else {
+        conv(cin, exp, 1, 1, 2, 0, 0, 0, st + 1, pad64(cin));
+        EOp d{};
+        d.kind = 1; d.cin = d.cout = exp; d.cin_p = d.cout_p = pad64(exp); d.ks = 3; d.stride = stride; d.act = 2; d.feature = st + 1;
+        d.w_off = take(static_cast<size_t>(9) * d.cin_p);
+        d.b_off = take(d.cin_p);
+        plan->ops.push_back(d);
+        EOp e{};
+        e.kind = 2; e.cin = e.cout = exp; e.cin_p = e.cout_p = pad64(exp); e.sq = cin / 4 > 1 ? cin / 4 : 1; e.feature = st + 1;
+        e.w_off = take(static_cast<size_t>(e.sq) * e.cin_p);
+        e.b_off = take(e.sq);
+        e.w2_off = take(static_cast<size_t>(e.cin_p) * e.sq);
+        e.b2_off = take(e.cin_p);
+        plan->ops.push_back(e);
+        if (e.cin_p > plan->max_expand_p) plan->max_expand_p = e.cin_p;
+        conv(exp, g.cout, 1, 1, 0, res, 1, 1, st + 1, pad64(exp));
+      }
+    }
+  }
+  plan->packed_floats = off;
+  *plan_out = plan;
+  return SPR_OK;
+}
+
+extern "C" void spr_effnet_plan_destroy(spr_effnet_plan* plan) { delete plan; }
+extern "C" int spr_effnet_num_ops(const spr_effnet_plan* plan) { return plan ? static_cast<int>(plan->ops.size()) : SPR_ERR_ARG; }
+extern "C" size_t spr_effnet_packed_bytes(const spr_effnet_plan* plan) { return plan ? plan->packed_floats * sizeof(float) : 0; }
+
+// info[16] = kind, cin, cout, cin_p, cout_p, ks, stride, act, res, sq, feature, then the four packed offsets (in floats,
+// each < 2^31) w, b, w2, b2, then block_end (1: last layer of a residual block or of the stem)
+extern "C" int spr_effnet_op_info(const spr_effnet_plan* plan, int32_t i, int32_t* info) {
+  if (!plan || !info || i < 0 || i >= static_cast<int>(plan->ops.size())) { set_error("spr_effnet_op_info: bad argument"); return SPR_ERR_ARG; }
+  const EOp& o = plan->ops[i];
+  const int32_t v[16] = {o.kind, o.cin, o.cout, o.cin_p, o.cout_p, o.ks, o.stride, o.act, o.res, o.sq, o.feature,
+                         static_cast<int32_t>(o.w_off), static_cast<int32_t>(o.b_off), static_cast<int32_t>(o.w2_off),
+                         static_cast<int32_t>(o.b2_off), o.block_end};
+  for (int k = 0; k < 16; ++k) info[k] = v[k];
+  return SPR_OK;
+}
+
+static void effnet_dims(const spr_effnet_plan* plan, int in_h, int in_w, int* c, int* h, int* w) {
+  int hh = in_h, ww = in_w, cc = 3;
+  for (const EOp& o : plan->ops) {
+    if (o.kind == 2) continue;
+    if (o.stride == 2) { hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1; }
+    cc = o.cout;
+  }
+  *c = cc; *h = hh; *w = ww;
+}
+
+extern "C" int spr_effnet_output_shape(const spr_effnet_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels,
+                                       int32_t* out_h, int32_t* out_w) {
+  if (!plan || !channels || !out_h || !out_w || in_h < 1 || in_w < 1) { set_error("spr_effnet_output_shape: bad argument"); return SPR_ERR_ARG; }
+  int c, h, w;
+  effnet_dims(plan, in_h, in_w, &c, &h, &w);
+  *channels = c; *out_h = h; *out_w = w;
+  return SPR_OK;
+}
+
+// four activation buffers as large as the largest tensor between layers + the normalised input + the squeeze-excitation
+// vectors (mean and factors)
+static size_t effnet_buf_floats(const spr_effnet_plan* plan, int64_t n, int in_h, int in_w) {
+  size_t best = static_cast<size_t>(n) * in_h * in_w * 16;
+  int hh = in_h, ww = in_w;
+  for (const EOp& o : plan->ops) {
+    if (o.kind == 2) continue;
+    if (o.stride == 2) { hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1; }
+    const size_t f = static_cast<size_t>(n) * hh * ww * o.cout_p;
+    if (f > best) best = f;
+  }
+  return best;
+}
+extern "C" size_t spr_effnet_workspace_bytes(const spr_effnet_plan* plan, int64_t n, int32_t in_h, int32_t in_w) {
+  if (!plan || n < 0) return 0;
+  const size_t buf = align_up(effnet_buf_floats(plan, n, in_h, in_w) * sizeof(float), 256);
+  return 4 * buf + 2 * align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256);
+}
+
+template <int KS, int STRIDE>
+static int launch_egemm(const EOp& o, const float* in, int64_t n, int h, int w, const float* pk, const float* res,
+                        const float* scale, int nchw, float* out, hipStream_t s) {
+  const int pad = KS / 2;
+  const int ho = (h + 2 * pad - KS) / STRIDE + 1, wo = (w + 2 * pad - KS) / STRIDE + 1;
+  const long long m = static_cast<long long>(n) * ho * wo;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<KS, STRIDE>), dim3(static_cast<unsigned>((m + kGM - 1) / kGM),
+                     static_cast<unsigned>(o.cout_p / kGN)), dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, o.cin_p,
+                     o.cout_p, pk + o.w_off, pk + o.b_off, res, o.act, nchw, out, scale, o.cout);
+  return check_launch("conv_gemm_kernel");
+}
+
+extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                                  int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                                  void* workspace, float* out, spr_stream_t stream) {
+  if (!plan) { set_error("spr_effnet_forward: null plan"); return SPR_ERR_ARG; }
+  if (n < 0 || n > 65535 || in_h < 32 || in_w < 32 || (in_channels != 1 && in_channels != 3)) {
+    set_error("spr_effnet_forward: bad sizes (n in [0, 65535], images at least 32 x 32, in_channels 1 or 3)");
+    return SPR_ERR_ARG;
+  }
+  if (n == 0) return SPR_OK;
+  if (!images || !mean3 || !inv_std3 || !packed || !out || !workspace) { set_error("spr_effnet_forward: null pointer"); return SPR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* pk = static_cast<const float*>(packed);
+  const size_t buf_bytes = align_up(effnet_buf_floats(plan, n, in_h, in_w) * sizeof(float), 256);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  float* x = reinterpret_cast<float*>(ws);                    // block input
+  float* t1 = reinterpret_cast<float*>(ws + buf_bytes);
+  float* t2 = reinterpret_cast<float*>(ws + 2 * buf_bytes);
+  float* y = reinterpret_cast<float*>(ws + 3 * buf_bytes);    // block output
+  float* pooled = reinterpret_cast<float*>(ws + 4 * buf_bytes);
+  float* factors = pooled + align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) / sizeof(float);
+  const size_t pixels = static_cast<size_t>(n) * in_h * in_w;
+  hipLaunchKernelGGL(enet_input_kernel, dim3(static_cast<unsigned>(std::min<size_t>((pixels + kThreads - 1) / kThreads, 65535 * 16))),
+                     dim3(kThreads), 0, s, images, pixels, in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1],
+                     inv_std3[2], x);
+  int rc = check_launch("enet_input_kernel");
+  if (rc != SPR_OK) return rc;
+  int h = in_h, w = in_w;
+  const float* cur = x;   // what the next layer reads
+  float* tmp[2] = {t1, t2};
+  int ti = 0;
+  const float* scale = nullptr;
+  for (size_t i = 0; i < plan->ops.size(); ++i) {
+    const EOp& o = plan->ops[i];
+    const bool last = i + 1 == plan->ops.size();
+    if (o.kind == 0) {
+      float* dst = last ? out : o.block_end ? y : tmp[ti];
+      const float* res = o.res ? x : nullptr;
+      const float* sc = o.scaled ? scale : nullptr;
+      if (o.ks == 3 && o.stride == 2) rc = launch_egemm<3, 2>(o, cur, n, h, w, pk, res, sc, last ? 1 : 0, dst, s);
+      else if (o.ks == 3) rc = launch_egemm<3, 1>(o, cur, n, h, w, pk, res, sc, last ? 1 : 0, dst, s);
+      else rc = launch_egemm<1, 1>(o, cur, n, h, w, pk, res, sc, last ? 1 : 0, dst, s);
+      if (rc != SPR_OK) return rc;
+      if (o.stride == 2) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+      if (o.block_end) {  // the block's output becomes the next block's input
+        float* old = x; x = y; y = old;
+        cur = x;
+        ti = 0;
+      } else {
+        cur = dst;
+        ti ^= 1;
+      }
+    } else if (o.kind == 1) {
+      float* dst = tmp[ti];
+      const int ho = (h - 1) / o.stride + 1, wo = (w - 1) / o.stride + 1;
+      const size_t total = static_cast<size_t>(n) * ho * wo * (o.cin_p / 4);
+      hipLaunchKernelGGL(enet_dw_kernel, dim3(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16))),
+                         dim3(kThreads), 0, s, cur, static_cast<int>(n), h, w, o.cin_p, o.stride, pk + o.w_off, pk + o.b_off, dst);
+      rc = check_launch("enet_dw_kernel");
+      if (rc != SPR_OK) return rc;
+      h = ho; w = wo;
+      cur = dst;
+      ti ^= 1;
+    } else {
+      hipLaunchKernelGGL(enet_pool_kernel, dim3(o.cin_p / 64, static_cast<unsigned>(n)), dim3(kThreads), 0, s, cur, h * w, o.cin_p,
+                         pooled);
+      rc = check_launch("enet_pool_kernel");
+      if (rc != SPR_OK) return rc;
+      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n)), dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off,
+                         pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
+      rc = check_launch("enet_fc_kernel");
+      if (rc != SPR_OK) return rc;
+      scale = factors;
+    }
   }
   return SPR_OK;
 }

@@ -43,10 +43,34 @@ _VGG_MODELS = {"VGG16": (0, VGG16_MEAN, VGG16_STD), "VGG19": (1, IMAGENET_MEAN, 
 # BUILD-DEFINED (BASELINE.json config 3; the reference has no ResNet branch): torchvision's resnet50 cut after `block` of its
 # top-level children [conv1, bn1, relu, maxpool, layer1, layer2, layer3] - block 5 / 6 / 7 - with the default transforms
 _RESNET_MODELS = {"ResNet50": (IMAGENET_MEAN, IMAGENET_STD)}
+# network.py:163-175: arch id of spr_effnet_plan_create, mean, std (EfficientNetV2_L was trained on 0.5 / 0.5)
+_EFFNET_MODELS = {"EfficientNetV2_S": (0, IMAGENET_MEAN, IMAGENET_STD), "EfficientNetV2_M": (1, IMAGENET_MEAN, IMAGENET_STD),
+                  "EfficientNetV2_L": (2, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))}
+EFFNET_BN_EPS = 1e-3  # torchvision's efficientnet_v2 builds its BatchNorm2d with eps = 1e-3
 _REFERENCE_MODELS = {"EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
                      "EfficientNet_B5", "EfficientNet_B7", "EfficientNetV2_S", "EfficientNetV2_M", "EfficientNetV2_L",
                      "DenseNet_201"}
 _warned = False
+
+
+def effnet_state_names(ops) -> list[tuple[str, str]]:
+    """Module names of the layers in a torchvision efficientnet_v2 state dict, in ``Model.effnet_ops`` order: (convolution,
+    BatchNorm) or, for a squeeze-excitation, (fc1, fc2).  Written from torchvision's module layout - features.0 = stem,
+    features.s = stage s, .l = block l of the stage, .block.k = its k-th sub-module - and not checked against a checkpoint:
+    none is available offline."""
+    names, layer, slot = [], {}, 0
+    for op in ops:
+        f = op["feature"]
+        if f == 0:
+            names.append(("features.0.0", "features.0.1"))
+            continue
+        pre = f"features.{f}.{layer.setdefault(f, 0)}.block.{slot}"
+        names.append((f"{pre}.fc1", f"{pre}.fc2") if op["kind"] == 2 else (f"{pre}.0", f"{pre}.1"))
+        slot += 1
+        if op["block_end"]:
+            layer[f] += 1
+            slot = 0
+    return names
 
 
 class Model:
@@ -60,7 +84,8 @@ class Model:
         self.clahe_tile_grid_size = tuple(model_cfg.get("clahe_tile_grid_size", (8, 8)))
         model_str = model_cfg["type"]
         self.resnet = model_str in _RESNET_MODELS
-        if model_str not in _VGG_MODELS and not self.resnet:
+        self.effnet = model_str in _EFFNET_MODELS
+        if model_str not in _VGG_MODELS and not self.resnet and not self.effnet:
             if model_str in _REFERENCE_MODELS:
                 raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); "
                                           f"use one of {sorted(_VGG_MODELS)}")
@@ -68,6 +93,8 @@ class Model:
         self.model_str = model_str
         if self.resnet:
             self.arch, (self.mean, self.std) = -1, _RESNET_MODELS[model_str]
+        elif self.effnet:
+            self.arch, self.mean, self.std = _EFFNET_MODELS[model_str]
         else:
             self.arch, self.mean, self.std = _VGG_MODELS[model_str]
         self.block = int(block)
@@ -79,6 +106,14 @@ class Model:
             device = TorchDevice()
         self.dev = device
         handle = C.c_void_p()
+        if self.effnet:
+            self.lib.check(self.lib.spr_effnet_plan_create(self.arch, self.block, C.byref(handle)))
+            self.handle = handle
+            self.n_convs = self.lib.spr_effnet_num_ops(handle)
+            if parameters is None:
+                parameters = self._load_effnet_parameters(config)
+            self._set_effnet_parameters(parameters)
+            return
         if self.resnet:
             self.lib.check(self.lib.spr_resnet_plan_create(self.block, C.byref(handle)))
             self.handle = handle
@@ -93,6 +128,89 @@ class Model:
         if parameters is None:
             parameters = self._load_parameters(config)
         self._set_parameters(parameters)
+
+    # ------------------------------------------------------------------ EfficientNetV2 (network.py:163-175)
+    def effnet_ops(self) -> list[dict]:
+        """The flattened layers of features[:block]: kind (0 convolution, 1 depthwise 3x3, 2 squeeze-excitation), real and
+        padded widths, kernel size, stride, activation, residual flag, hidden width, index into ``features`` and the offsets
+        (floats) of the layer's parameters in the packed buffer."""
+        keys = ("kind", "cin", "cout", "cin_p", "cout_p", "ks", "stride", "act", "res", "sq", "feature", "w_off", "b_off",
+                "w2_off", "b2_off", "block_end")
+        out = []
+        for i in range(self.n_convs):
+            info = (C.c_int32 * 16)()
+            self.lib.check(self.lib.spr_effnet_op_info(self.handle, i, info))
+            out.append(dict(zip(keys, list(info))))
+        return out
+
+    def _load_effnet_parameters(self, config):
+        global _warned
+        path = config.get("mi355x", {}).get("weights", "")
+        ops = self.effnet_ops()
+        if path:
+            import torch
+
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            params = []
+            for op, names in zip(ops, effnet_state_names(ops)):
+                if op["kind"] == 2:
+                    fc1, fc2 = names
+                    params.append(tuple(state[f"{m}.{n}"].float().numpy() for m in (fc1, fc2) for n in ("weight", "bias")))
+                else:
+                    conv, bn = names
+                    w = state[f"{conv}.weight"].float().numpy()
+                    params.append((w, np.zeros(w.shape[0], np.float32)) + tuple(
+                        state[f"{bn}.{n}"].float().numpy() for n in ("weight", "bias", "running_mean", "running_var")))
+            return params
+        if not _warned:
+            print(f"shoeprint_image_retrieval_amd: no [mi355x].weights given — using seeded synthetic {self.model_str} "
+                  "weights (pretrained ImageNet weights cannot be downloaded offline)", file=sys.stderr)
+            _warned = True
+        return synth.effnet_parameters(1234, ops)
+
+    def _set_effnet_parameters(self, parameters):
+        ops = self.effnet_ops()
+        if len(parameters) < len(ops):
+            raise ValueError(f"{len(ops)} layers need parameters, got {len(parameters)}")
+        packed = np.zeros(self.lib.spr_effnet_packed_bytes(self.handle) // 4, np.float32)
+        for op, p in zip(ops, parameters):
+            p = [np.asarray(t, dtype=np.float32) for t in p]
+            if op["kind"] == 2:
+                w1, b1, w2, b2 = p
+                c, cp, sq = op["cin"], op["cin_p"], op["sq"]
+                if w1.reshape(-1).size != sq * c or w2.reshape(-1).size != c * sq:
+                    raise ValueError(f"squeeze-excitation of width {c}: parameters do not match (hidden width {sq})")
+                a = np.zeros((sq, cp), np.float32); a[:, :c] = w1.reshape(sq, c)
+                b = np.zeros((cp, sq), np.float32); b[:c] = w2.reshape(c, sq)
+                bb = np.zeros(cp, np.float32); bb[:c] = b2
+                packed[op["w_off"]:op["w_off"] + a.size] = a.ravel()
+                packed[op["b_off"]:op["b_off"] + sq] = b1
+                packed[op["w2_off"]:op["w2_off"] + b.size] = b.ravel()
+                packed[op["b2_off"]:op["b2_off"] + cp] = bb
+                continue
+            w, b, gamma, beta, mu, var = p
+            scale = gamma / np.sqrt(var + np.float32(EFFNET_BN_EPS))  # eval-mode BatchNorm folded into the convolution
+            w = w * scale[:, None, None, None]
+            b = (b - mu) * scale + beta
+            ks, cin, cout, cin_p, cout_p = op["ks"], op["cin"], op["cout"], op["cin_p"], op["cout_p"]
+            if op["kind"] == 1:
+                if w.shape != (cin, 1, 3, 3):
+                    raise ValueError(f"depthwise parameter shape {w.shape} does not match width {cin}")
+                a = np.zeros((9, cin_p), np.float32); a[:, :cin] = w.reshape(cin, 9).T
+                bb = np.zeros(cin_p, np.float32); bb[:cin] = b
+                packed[op["w_off"]:op["w_off"] + a.size] = a.ravel()
+                packed[op["b_off"]:op["b_off"] + cin_p] = bb
+                continue
+            if w.shape != (cout, cin, ks, ks):
+                raise ValueError(f"parameter shape {w.shape} does not match conv {cin}->{cout} {ks}x{ks}")
+            wp = np.zeros((cout_p, ks * ks, cin_p), np.float32)
+            wp[:cout, :, :cin] = w.reshape(cout, cin, ks * ks).transpose(0, 2, 1)  # K index = tap * cin_p + c
+            k = ks * ks * cin_p
+            wp = wp.reshape(cout_p // 64, 64, k // 16, 16).transpose(0, 2, 1, 3)  # [cout/64][K/16][64][16]
+            bb = np.zeros(cout_p, np.float32); bb[:cout] = b
+            packed[op["w_off"]:op["w_off"] + wp.size] = np.ascontiguousarray(wp).ravel()
+            packed[op["b_off"]:op["b_off"] + cout_p] = bb
+        self.packed = self.dev.to_device(packed)
 
     # ------------------------------------------------------------------ ResNet50 (build-defined)
     def conv_specs(self) -> list[tuple[int, int, int, int, int]]:
@@ -228,7 +346,8 @@ class Model:
     # ------------------------------------------------------------------ shapes
     def output_shape(self, in_h: int, in_w: int) -> tuple[int, int, int]:
         c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
-        fn = self.lib.spr_resnet_output_shape if self.resnet else self.lib.spr_vgg16_output_shape
+        fn = (self.lib.spr_effnet_output_shape if self.effnet else
+              self.lib.spr_resnet_output_shape if self.resnet else self.lib.spr_vgg16_output_shape)
         self.lib.check(fn(self.handle, in_h, in_w, C.byref(c), C.byref(h), C.byref(w)))
         return c.value, h.value, w.value
 
@@ -240,8 +359,10 @@ class Model:
         n, h, w = shape[0], shape[1], shape[2]
         c, oh, ow = self.output_shape(h, w)
         out = dev.empty((n, c, oh, ow), np.float32)
-        ws_fn = self.lib.spr_resnet_workspace_bytes if self.resnet else self.lib.spr_vgg16_workspace_bytes
-        fwd = self.lib.spr_resnet_forward if self.resnet else self.lib.spr_vgg16_forward
+        ws_fn = (self.lib.spr_effnet_workspace_bytes if self.effnet else
+                 self.lib.spr_resnet_workspace_bytes if self.resnet else self.lib.spr_vgg16_workspace_bytes)
+        fwd = (self.lib.spr_effnet_forward if self.effnet else
+               self.lib.spr_resnet_forward if self.resnet else self.lib.spr_vgg16_forward)
         ws = dev.empty_bytes(max(16, ws_fn(self.handle, n, h, w)))
         mean = (C.c_float * 3)(*self.mean)
         inv_std = (C.c_float * 3)(*[np.float32(1.0) / np.float32(s) for s in self.std])
@@ -254,7 +375,7 @@ class Model:
         ``model.features`` like ``block``, each just behind a ReLU (16 = conv3_3, 23 = conv4_3, 30 = conv5_3 for VGG16) -
         as float32 device arrays [N, C_l, h_l, w_l], in that order; a tap equal to ``block`` is the network's output.
         Multi-layer scoring (BASELINE config 5) feeds on this: the reference would run the extractor once per block."""
-        if self.resnet:
+        if self.resnet or self.effnet:
             raise NotImplementedError("feature taps are built for the plain VGG backbones")
         dev = self.dev
         n, h, w = dev.shape(images_dev)[:3]
@@ -361,7 +482,8 @@ class Model:
 
     def close(self):
         if getattr(self, "handle", None):
-            (self.lib.spr_resnet_plan_destroy if self.resnet else self.lib.spr_vgg16_plan_destroy)(self.handle)
+            (self.lib.spr_effnet_plan_destroy if getattr(self, "effnet", False) else
+             self.lib.spr_resnet_plan_destroy if self.resnet else self.lib.spr_vgg16_plan_destroy)(self.handle)
             self.handle = None
 
     def __del__(self):  # pragma: no cover

@@ -173,6 +173,35 @@ def resnet_parameters(seed: int, conv_specs):
     return out
 
 
+def effnet_parameters(seed: int, ops):
+    """Seeded parameters of an EfficientNetV2 truncation (``Model.effnet_ops``): per convolution / depthwise layer a He-normal
+    weight, a zero bias (torchvision's have none) and BatchNorm2d (gamma, beta, running mean, running variance); per
+    squeeze-excitation (fc1 weight, bias, fc2 weight, bias).  Projections into a residual sum get gamma ~ 0.5."""
+    def normal(i, k, n):
+        return irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 9000 + 8 * i + k), np.arange(n, dtype=np.int64)).astype(np.float32) / np.float32(37837.0)
+
+    out = []
+    for i, op in enumerate(ops):
+        cin, cout, ks = op["cin"], op["cout"], op["ks"]
+        if op["kind"] == 2:
+            sq = op["sq"]
+            w1 = (normal(i, 0, sq * cin) * np.float32(np.sqrt(1.0 / cin))).reshape(sq, cin, 1, 1)
+            w2 = (normal(i, 1, cin * sq) * np.float32(np.sqrt(1.0 / sq))).reshape(cin, sq, 1, 1)
+            out.append((w1, np.float32(0.1) * normal(i, 2, sq), w2, np.float32(1.0) + np.float32(0.3) * normal(i, 3, cin)))
+            continue
+        fan = 9 if op["kind"] == 1 else cin * ks * ks
+        shape = (cin, 1, 3, 3) if op["kind"] == 1 else (cout, cin, ks, ks)
+        n_out = shape[0]
+        w = (normal(i, 0, int(np.prod(shape))) * np.float32(np.sqrt(2.0 / fan))).reshape(shape)
+        u = [normal(i, 1 + k, n_out) for k in range(4)]
+        gamma = (np.float32(0.5) if op["kind"] == 0 and op["act"] == 0 else np.float32(1.0)) * \
+            (np.float32(1.0) + np.float32(0.1) * np.clip(u[0], -3, 3))
+        out.append(tuple(np.ascontiguousarray(t, dtype=np.float32) for t in
+                         (w, np.zeros(n_out, np.float32), gamma, np.float32(0.05) * u[1], np.float32(0.1) * u[2],
+                          np.float32(1.0) + np.float32(0.4) * np.tanh(u[3]))))
+    return out
+
+
 def bfloat16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bfloat16 bit patterns (uint16), round to nearest even — the storage form the scorer
     accepts for bf16 features (numpy has no bfloat16 type)."""

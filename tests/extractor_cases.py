@@ -65,6 +65,32 @@ def check_resnet50(block, hw, device, lib, n_images=2, tol=5e-5):
     m.close()
 
 
+def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=False):
+    """An EfficientNetV2 truncation features[:block] (the reference's run.toml default is EfficientNetV2_M, blocks 4 .. 6)
+    against the torch-CPU oracle with the same seeded parameters; parity unpinned (no torchvision offline).  Tolerance:
+    relative to the largest activation."""
+    from oracle import effnet_oracle
+
+    cfg = {"model": dict(CFG["model"], type=model_str), "comparison": CFG["comparison"]}
+    m = network.Model(cfg, block, device=device, library=lib)
+    ops = m.effnet_ops()
+    params = synth.effnet_parameters(1234, ops)
+    names = network.effnet_state_names(ops)
+    assert names[0] == ("features.0.0", "features.0.1") and len(names) == len(ops)
+    assert all(n[0].startswith(f"features.{op['feature']}.") for n, op in zip(names, ops))
+    if rgb:
+        imgs = np.stack([np.stack([synth.shoeprint_image(8 + c, i, *hw) for c in range(3)], axis=-1) for i in range(n_images)])
+    else:
+        imgs = np.stack([synth.shoeprint_image(8, i, *hw) for i in range(n_images)])
+    got = device.to_host(m.extract_device(device.to_device(imgs), in_channels=3 if rgb else 1))
+    assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    for i in range(n_images):
+        ref = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std)
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+    m.close()
+
+
 def check_multi_layer_pipeline(device, lib, scorer, hw=(64, 48), taps=(9, 14, 16), n_gallery=7, n_queries=3, batch=3):
     """BASELINE config 5 in miniature: one extractor pass with feature taps, per-layer scoring chains on their own
     streams (gallery in batches, the last one ragged), fusion on the device - against the oracle chain: torch-CPU features

@@ -33,6 +33,15 @@ def test_emu_resnet50_layer1():
     ec.check_resnet50(5, (40, 36), HostDevice(), emu_library(), n_images=1)
 
 
+@pytest.mark.parametrize("model,block,hw,rgb", [("EfficientNetV2_M", 2, (40, 36), False), ("EfficientNetV2_M", 5, (40, 32), False),
+                                                ("EfficientNetV2_S", 3, (34, 32), True)])
+def test_emu_efficientnet_v2(model, block, hw, rgb):
+    """EfficientNetV2 truncations under emulation: stem, FusedMBConv stages (3x3 expansion + 1x1 projection on the GEMM
+    kernel, channel counts padded to 64), and with block 5 an MBConv stage (1x1 expansion, depthwise 3x3 / stride 2,
+    squeeze-excitation, scaled 1x1 projection)."""
+    ec.check_effnet(model, block, hw, HostDevice(), emu_library(), n_images=1, rgb=rgb)
+
+
 def test_emu_multi_layer_pipeline():
     ec.check_multi_layer_pipeline(HostDevice(), emu_library(), emu_scorer("fft"), hw=(40, 32), n_gallery=5, n_queries=2, batch=2)
 

@@ -260,6 +260,16 @@ def test_resnet50_extractor(torch_dev, lib, block, hw):
     ec.check_resnet50(block, hw, torch_dev, lib, n_images=1 if block == 7 else 2)
 
 
+@pytest.mark.parametrize("model,block,hw", [("EfficientNetV2_M", 4, (128, 96)), ("EfficientNetV2_M", 6, (512, 256)),
+                                            ("EfficientNetV2_S", 5, (96, 64)), ("EfficientNetV2_L", 5, (64, 64))])
+def test_efficientnet_v2_extractor(torch_dev, lib, model, block, hw):
+    """EfficientNetV2 truncations (the reference's run.toml default: EfficientNetV2_M, blocks 4 .. 6) - block 6 at the full
+    512x256 print, [176, 32, 16] out - vs torch-CPU with the same seeded parameters."""
+    import extractor_cases as ec
+
+    ec.check_effnet(model, block, hw, torch_dev, lib, n_images=1 if hw[0] >= 512 else 2, tol=1e-4)
+
+
 def test_multi_layer_pipeline(torch_dev, lib, fft_scorer):
     """Config 5: conv3_3 + conv4_3 + conv5_3 taps of one VGG16 pass, scored on separate streams, fused on the device."""
     import extractor_cases as ec
