@@ -11,8 +11,9 @@ library's ``spr_vgg16_forward`` (implicit-GEMM 3x3 convolutions on the fp32 matr
 ReLU / max-pool fused, pre-processing fused into the first layer) and — unlike the reference's one
 image per launch (network.py:228) — runs whole batches; ``extract_device`` keeps the features in HBM
 for the scorer.  Unknown ``model.type`` raises ``LookupError("Model string not found")`` as the
-reference does (network.py:180-182); the reference's EfficientNet* / DenseNet backbones are not built
-and raise ``NotImplementedError``.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
+reference does (network.py:180-182).  ``EfficientNetV2_S / _M / _L`` (network.py:163-175; run.toml's default) run on
+``spr_effnet_forward`` (stem, FusedMBConv and MBConv stages; BatchNorm folded and parameters packed here); the reference's
+EfficientNet_B* and DenseNet_201 backbones are not built and raise ``NotImplementedError``.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
 layer3 extractor, the reference has none): torchvision's resnet50 cut after ``block`` of its top-level children
 [conv1, bn1, relu, maxpool, layer1, layer2, layer3], block = 5 / 6 / 7, ImageNet mean / std.
 
@@ -88,7 +89,7 @@ class Model:
         if model_str not in _VGG_MODELS and not self.resnet and not self.effnet:
             if model_str in _REFERENCE_MODELS:
                 raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); "
-                                          f"use one of {sorted(_VGG_MODELS)}")
+                                          f"use one of {sorted(_VGG_MODELS) + sorted(_EFFNET_MODELS)}")
             raise LookupError("Model string not found")  # network.py:180-182
         self.model_str = model_str
         if self.resnet:

@@ -156,7 +156,7 @@ def check_reference_surface(device, lib):
         np.testing.assert_allclose(fm, ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
     single = m.get_feature_maps(imgs[1])
     np.testing.assert_array_equal(single, maps[1])
-    for bad, exc in (("NoSuchNet", LookupError), ("EfficientNetV2_M", NotImplementedError), ("DenseNet_201", NotImplementedError)):
+    for bad, exc in (("NoSuchNet", LookupError), ("EfficientNet_B4", NotImplementedError), ("DenseNet_201", NotImplementedError)):
         cfg = {"model": dict(CFG["model"], type=bad)}
         try:
             network.Model(cfg, 5, device=device, library=lib)
