@@ -341,3 +341,39 @@ def test_run_driver_on_an_image_directory(tmp_path, capsys):
         feats = lambda ims: [vgg_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), block, params) for im in ims]
         want += [int(r) for r in ncc_oracle.compare_maps(feats(queries), feats(gallery), matches, cfg)]
     assert got == want
+
+
+def test_run_driver_with_the_reference_default_model(tmp_path, capsys):
+    """The [model] and [comparison] sections of the reference's own run.toml - EfficientNetV2_M, start_block 6, end_block 4,
+    block 5 skipped, rotated and scaled query variants - on a two-cluster image directory == dataloader -> oracle chain
+    (EfficientNetV2 oracle with the same seeded parameters, NCC oracle with the same variants)."""
+    import dataset_util
+    import run_mi355x
+    from oracle import clahe_oracle, effnet_oracle, ncc_oracle
+    from shoeprint_image_retrieval_amd import network, synth
+    from shoeprint_image_retrieval_amd.dataloader import Dataloader
+
+    case = next(c for c in dataset_util.CASES if c["name"] == "wvu_split")
+    cfg = dataset_util.write_dataset(str(tmp_path), case)
+    toml = tmp_path / "run.toml"
+    toml.write_text(
+        f'[dataset]\ndir = "{tmp_path}"\ntype = "WVU2019"\ncrop = {case["crop"]}\nn_processes = 3\nn_clusters = 2\n'
+        f'cluster_minimise_tolerance = 0.05\n[model]\ntype = "EfficientNetV2_M"\nclahe_clip_limit = 2.0\n'
+        f'clahe_tile_grid_size = [8, 8]\nstart_block = 6\nend_block = 4\nskip_blocks = [5]\nminimum_dim = 120\nmaximum_dim = 200\n'
+        f'[comparison]\nn_processes = 2\nrotations = [-9, 3, 180]\nscales = [1.04]\n')
+    got = run_mi355x.main(str(toml))
+    assert "rank-1:" in capsys.readouterr().out
+    from shoeprint_image_retrieval_amd.config import load_config
+
+    config = load_config(str(toml))
+    want, blocks = [], set()
+    for queries, gallery, matches, block in Dataloader(config):
+        blocks.add(block)
+        m = network.Model(config, block)
+        ops = m.effnet_ops()
+        params = synth.effnet_parameters(1234, ops)
+        feats = lambda ims: [effnet_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), ops, params, m.mean, m.std)
+                             for im in ims]
+        want += [int(r) for r in ncc_oracle.compare_maps(feats(queries), feats(gallery), matches, config)]
+        m.close()
+    assert blocks <= {4, 6} and got == want
