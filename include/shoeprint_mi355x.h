@@ -275,8 +275,8 @@ int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, int64_t n, 
 
 /* ------------------------------------------------------------------ EfficientNetV2 feature extractor
  * network.py:163-175 (model choice), :185-186 (`list(model.features.children())[:block]`), :60-71 / :74-87 (transforms).
- * arch: 0 = EfficientNetV2_S, 1 = EfficientNetV2_M (the reference's run.toml default), 2 = EfficientNetV2_L; block in
- * [1, stages + 1]: the stem and block - 1 stages of torchvision's efficientnet_v2 (the closing 1x1 convolution is not built).
+ * arch: 0 = EfficientNetV2_S, 1 = EfficientNetV2_M (the reference's run.toml default), 2 = EfficientNetV2_L, 3 .. 8 =
+ * EfficientNet_B1, B2, B3, B4, B5, B7 (network.py:139-162); block in [1, stages + 1]: the stem and block - 1 stages of torchvision's efficientnet_v2 (the closing 1x1 convolution is not built).
  * The plan flattens the graph into layers (spr_effnet_op_info: int32[16] = kind {0 convolution, 1 depthwise 3x3, 2 squeeze-
  * excitation}, cin, cout, cin_p, cout_p, ksize, stride, act {0 none, 2 SiLU}, res, sq, feature index, offsets in floats of
  * w, b, w2, b2 in the packed buffer, block_end).  The caller folds eval-mode BatchNorm (eps 1e-3) into the convolutions and writes

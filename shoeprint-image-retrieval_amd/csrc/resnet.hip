@@ -19,6 +19,7 @@
 //                    residual add, ReLU.
 // Arithmetic: 17.13 GFLOP per 512x256 image through layer3; bound: fp32 MFMA 157 TFLOP/s.
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <vector>
 
@@ -252,12 +253,12 @@ enet_input_kernel(const uint8_t* __restrict__ images, size_t pixels, int in_chan
   }
 }
 
-// depthwise 3x3, stride 1 or 2, pad 1, + bias + SiLU.  One work-item = four channels of one output pixel.
+// depthwise ks x ks (3 or 5), stride 1 or 2, pad ks / 2, + bias + SiLU.  One work-item = four channels of one output pixel.
 // weights [tap][C] (channels contiguous), C a multiple of 64
 __global__ void __launch_bounds__(kThreads)
-enet_dw_kernel(const float* __restrict__ in, int n_img, int H, int W, int C, int stride, const float* __restrict__ wts,
+enet_dw_kernel(const float* __restrict__ in, int n_img, int H, int W, int C, int stride, int ks, const float* __restrict__ wts,
                const float* __restrict__ bias, float* __restrict__ out) {
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, pad = ks / 2;
   const int c4 = C / 4;
   const size_t total = static_cast<size_t>(n_img) * Ho * Wo * c4;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
@@ -268,12 +269,12 @@ enet_dw_kernel(const float* __restrict__ in, int n_img, int H, int W, int C, int
     const int oy = static_cast<int>(p % Ho);
     const size_t img = p / Ho;
     float4 acc = *reinterpret_cast<const float4*>(bias + c);
-    for (int dy = 0; dy < 3; ++dy)
-      for (int dx = 0; dx < 3; ++dx) {
-        const int y = oy * stride + dy - 1, x = ox * stride + dx - 1;
+    for (int dy = 0; dy < ks; ++dy)
+      for (int dx = 0; dx < ks; ++dx) {
+        const int y = oy * stride + dy - pad, x = ox * stride + dx - pad;
         if (y < 0 || y >= H || x < 0 || x >= W) continue;
         const float4 v = *reinterpret_cast<const float4*>(in + ((img * H + y) * static_cast<size_t>(W) + x) * C + c);
-        const float4 w = *reinterpret_cast<const float4*>(wts + static_cast<size_t>(dy * 3 + dx) * C + c);
+        const float4 w = *reinterpret_cast<const float4*>(wts + static_cast<size_t>(dy * ks + dx) * C + c);
         acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y); acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
       }
     float4 o;
@@ -532,14 +533,26 @@ struct EOp {
   size_t w_off, b_off, w2_off, b2_off;  // floats into the packed buffer (multiples of 4)
 };
 
-struct EStage { int fused, expand, stride, cin, cout, layers; };
+struct EStage { int fused, expand, stride, cin, cout, layers, ks; };
 
-const EStage kV2S[] = {{1, 1, 1, 24, 24, 2}, {1, 4, 2, 24, 48, 4}, {1, 4, 2, 48, 64, 4}, {0, 4, 2, 64, 128, 6},
-                       {0, 6, 1, 128, 160, 9}, {0, 6, 2, 160, 256, 15}};
-const EStage kV2M[] = {{1, 1, 1, 24, 24, 3}, {1, 4, 2, 24, 48, 5}, {1, 4, 2, 48, 80, 5}, {0, 4, 2, 80, 160, 7},
-                       {0, 6, 1, 160, 176, 14}, {0, 6, 2, 176, 304, 18}, {0, 6, 1, 304, 512, 5}};
-const EStage kV2L[] = {{1, 1, 1, 32, 32, 4}, {1, 4, 2, 32, 64, 7}, {1, 4, 2, 64, 96, 7}, {0, 4, 2, 96, 192, 10},
-                       {0, 6, 1, 192, 224, 19}, {0, 6, 2, 224, 384, 25}, {0, 6, 1, 384, 640, 7}};
+const EStage kV2S[] = {{1, 1, 1, 24, 24, 2, 3}, {1, 4, 2, 24, 48, 4, 3}, {1, 4, 2, 48, 64, 4, 3}, {0, 4, 2, 64, 128, 6, 3},
+                       {0, 6, 1, 128, 160, 9, 3}, {0, 6, 2, 160, 256, 15, 3}};
+const EStage kV2M[] = {{1, 1, 1, 24, 24, 3, 3}, {1, 4, 2, 24, 48, 5, 3}, {1, 4, 2, 48, 80, 5, 3}, {0, 4, 2, 80, 160, 7, 3},
+                       {0, 6, 1, 160, 176, 14, 3}, {0, 6, 2, 176, 304, 18, 3}, {0, 6, 1, 304, 512, 5, 3}};
+const EStage kV2L[] = {{1, 1, 1, 32, 32, 4, 3}, {1, 4, 2, 32, 64, 7, 3}, {1, 4, 2, 64, 96, 7, 3}, {0, 4, 2, 96, 192, 10, 3},
+                       {0, 6, 1, 192, 224, 19, 3}, {0, 6, 2, 224, 384, 25, 3}, {0, 6, 1, 384, 640, 7, 3}};
+// EfficientNet_B0's stages (all MBConv); B1 .. B7 scale the widths and depths (network.py:139-162)
+const EStage kB0[] = {{0, 1, 1, 32, 16, 1, 3}, {0, 6, 2, 16, 24, 2, 3}, {0, 6, 2, 24, 40, 2, 5}, {0, 6, 2, 40, 80, 3, 3},
+                      {0, 6, 1, 80, 112, 3, 5}, {0, 6, 2, 112, 192, 4, 5}, {0, 6, 1, 192, 320, 1, 3}};
+// arch 3 .. 8 = EfficientNet_B1, B2, B3, B4, B5, B7: width and depth multipliers in tenths
+const int kBWidth[6] = {10, 11, 12, 14, 16, 20}, kBDepth[6] = {11, 12, 14, 18, 22, 31};
+
+inline int make_divisible8(double v) {  // torchvision's _make_divisible(v, 8)
+  int n = static_cast<int>(v + 4.0) / 8 * 8;
+  if (n < 8) n = 8;
+  if (n < 0.9 * v) n += 8;
+  return n;
+}
 
 inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
@@ -555,9 +568,23 @@ struct spr_effnet_plan {
 extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_plan** plan_out) {
   if (!plan_out) { set_error("spr_effnet_plan_create: null pointer"); return SPR_ERR_ARG; }
   *plan_out = nullptr;
+  EStage scaled[7];
   const EStage* stages = arch == 0 ? kV2S : arch == 1 ? kV2M : arch == 2 ? kV2L : nullptr;
   const int n_stages = arch == 0 ? 6 : 7;
-  if (!stages) { set_error("spr_effnet_plan_create: arch %d (0 = EfficientNetV2_S, 1 = _M, 2 = _L)", arch); return SPR_ERR_ARG; }
+  if (arch >= 3 && arch <= 8) {
+    const double wm = kBWidth[arch - 3] / 10.0, dm = kBDepth[arch - 3] / 10.0;
+    for (int i = 0; i < 7; ++i) {
+      scaled[i] = kB0[i];
+      scaled[i].cin = make_divisible8(kB0[i].cin * wm);
+      scaled[i].cout = make_divisible8(kB0[i].cout * wm);
+      scaled[i].layers = static_cast<int>(std::ceil(kB0[i].layers * dm - 1e-9));
+    }
+    stages = scaled;
+  }
+  if (!stages) {
+    set_error("spr_effnet_plan_create: arch %d (0 .. 2 = EfficientNetV2_S / _M / _L, 3 .. 8 = EfficientNet_B1 / B2 / B3 / B4 / B5 / B7)", arch);
+    return SPR_ERR_ARG;
+  }
   if (block < 1 || block > n_stages + 1) {
     set_error("spr_effnet_plan_create: block %d: features[:block] with block in [1, %d] (the last 1x1 convolution is not built)",
               block, n_stages + 1);
@@ -582,7 +609,8 @@ extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_pl
     const EStage& g = stages[st];
     for (int l = 0; l < g.layers; ++l) {
       const int cin = l == 0 ? g.cin : g.cout, stride = l == 0 ? g.stride : 1;
-      const int exp = cin * g.expand, res = stride == 1 && cin == g.cout;
+      const int exp = arch >= 3 ? make_divisible8(static_cast<double>(cin) * g.expand) : cin * g.expand;
+      const int res = stride == 1 && cin == g.cout;
       if (g.fused) {
         if (g.expand == 1) {
           conv(cin, g.cout, 3, stride, 2, res, 0, 1, st + 1, pad64(cin));
@@ -591,10 +619,10 @@ extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_pl
           conv(exp, g.cout, 1, 1, 0, res, 0, 1, st + 1, pad64(exp));
         }
       } else {
-        conv(cin, exp, 1, 1, 2, 0, 0, 0, st + 1, pad64(cin));
+        if (exp != cin) conv(cin, exp, 1, 1, 2, 0, 0, 0, st + 1, pad64(cin));  // (no expansion convolution at ratio 1)
         EOp d{};
-        d.kind = 1; d.cin = d.cout = exp; d.cin_p = d.cout_p = pad64(exp); d.ks = 3; d.stride = stride; d.act = 2; d.feature = st + 1;
-        d.w_off = take(static_cast<size_t>(9) * d.cin_p);
+        d.kind = 1; d.cin = d.cout = exp; d.cin_p = d.cout_p = pad64(exp); d.ks = g.ks; d.stride = stride; d.act = 2; d.feature = st + 1;
+        d.w_off = take(static_cast<size_t>(g.ks) * g.ks * d.cin_p);
         d.b_off = take(d.cin_p);
         plan->ops.push_back(d);
         EOp e{};
@@ -736,7 +764,7 @@ extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, 
       const int ho = (h - 1) / o.stride + 1, wo = (w - 1) / o.stride + 1;
       const size_t total = static_cast<size_t>(n) * ho * wo * (o.cin_p / 4);
       hipLaunchKernelGGL(enet_dw_kernel, dim3(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16))),
-                         dim3(kThreads), 0, s, cur, static_cast<int>(n), h, w, o.cin_p, o.stride, pk + o.w_off, pk + o.b_off, dst);
+                         dim3(kThreads), 0, s, cur, static_cast<int>(n), h, w, o.cin_p, o.stride, o.ks, pk + o.w_off, pk + o.b_off, dst);
       rc = check_launch("enet_dw_kernel");
       if (rc != SPR_OK) return rc;
       h = ho; w = wo;

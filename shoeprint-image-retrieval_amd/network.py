@@ -11,9 +11,10 @@ library's ``spr_vgg16_forward`` (implicit-GEMM 3x3 convolutions on the fp32 matr
 ReLU / max-pool fused, pre-processing fused into the first layer) and — unlike the reference's one
 image per launch (network.py:228) — runs whole batches; ``extract_device`` keeps the features in HBM
 for the scorer.  Unknown ``model.type`` raises ``LookupError("Model string not found")`` as the
-reference does (network.py:180-182).  ``EfficientNetV2_S / _M / _L`` (network.py:163-175; run.toml's default) run on
-``spr_effnet_forward`` (stem, FusedMBConv and MBConv stages; BatchNorm folded and parameters packed here); the reference's
-EfficientNet_B* and DenseNet_201 backbones are not built and raise ``NotImplementedError``.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
+reference does (network.py:180-182).  ``EfficientNetV2_S / _M / _L`` (network.py:163-175; run.toml's default) and
+``EfficientNet_B1 .. B5, B7`` (network.py:139-162) run on ``spr_effnet_forward`` (stem, FusedMBConv and MBConv stages;
+BatchNorm folded and parameters packed here); the reference's DenseNet_201 is not built and raises
+``NotImplementedError``.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
 layer3 extractor, the reference has none): torchvision's resnet50 cut after ``block`` of its top-level children
 [conv1, bn1, relu, maxpool, layer1, layer2, layer3], block = 5 / 6 / 7, ImageNet mean / std.
 
@@ -45,9 +46,13 @@ _VGG_MODELS = {"VGG16": (0, VGG16_MEAN, VGG16_STD), "VGG19": (1, IMAGENET_MEAN, 
 # top-level children [conv1, bn1, relu, maxpool, layer1, layer2, layer3] - block 5 / 6 / 7 - with the default transforms
 _RESNET_MODELS = {"ResNet50": (IMAGENET_MEAN, IMAGENET_STD)}
 # network.py:163-175: arch id of spr_effnet_plan_create, mean, std (EfficientNetV2_L was trained on 0.5 / 0.5)
-_EFFNET_MODELS = {"EfficientNetV2_S": (0, IMAGENET_MEAN, IMAGENET_STD), "EfficientNetV2_M": (1, IMAGENET_MEAN, IMAGENET_STD),
-                  "EfficientNetV2_L": (2, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))}
-EFFNET_BN_EPS = 1e-3  # torchvision's efficientnet_v2 builds its BatchNorm2d with eps = 1e-3
+# network.py:139-175: arch id of spr_effnet_plan_create, mean, std (EfficientNetV2_L was trained on 0.5 / 0.5), BatchNorm eps
+# (torchvision builds efficientnet_v2_* and efficientnet_b5 / b6 / b7 with eps = 1e-3, the others with the default 1e-5)
+_EFFNET_MODELS = {"EfficientNetV2_S": (0, IMAGENET_MEAN, IMAGENET_STD, 1e-3), "EfficientNetV2_M": (1, IMAGENET_MEAN, IMAGENET_STD, 1e-3),
+                  "EfficientNetV2_L": (2, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 1e-3),
+                  "EfficientNet_B1": (3, IMAGENET_MEAN, IMAGENET_STD, 1e-5), "EfficientNet_B2": (4, IMAGENET_MEAN, IMAGENET_STD, 1e-5),
+                  "EfficientNet_B3": (5, IMAGENET_MEAN, IMAGENET_STD, 1e-5), "EfficientNet_B4": (6, IMAGENET_MEAN, IMAGENET_STD, 1e-5),
+                  "EfficientNet_B5": (7, IMAGENET_MEAN, IMAGENET_STD, 1e-3), "EfficientNet_B7": (8, IMAGENET_MEAN, IMAGENET_STD, 1e-3)}
 _REFERENCE_MODELS = {"EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
                      "EfficientNet_B5", "EfficientNet_B7", "EfficientNetV2_S", "EfficientNetV2_M", "EfficientNetV2_L",
                      "DenseNet_201"}
@@ -95,7 +100,7 @@ class Model:
         if self.resnet:
             self.arch, (self.mean, self.std) = -1, _RESNET_MODELS[model_str]
         elif self.effnet:
-            self.arch, self.mean, self.std = _EFFNET_MODELS[model_str]
+            self.arch, self.mean, self.std, self.bn_eps = _EFFNET_MODELS[model_str]
         else:
             self.arch, self.mean, self.std = _VGG_MODELS[model_str]
         self.block = int(block)
@@ -130,7 +135,7 @@ class Model:
             parameters = self._load_parameters(config)
         self._set_parameters(parameters)
 
-    # ------------------------------------------------------------------ EfficientNetV2 (network.py:163-175)
+    # ------------------------------------------------------------------ EfficientNet B1 .. B7 and V2 (network.py:139-175)
     def effnet_ops(self) -> list[dict]:
         """The flattened layers of features[:block]: kind (0 convolution, 1 depthwise 3x3, 2 squeeze-excitation), real and
         padded widths, kernel size, stride, activation, residual flag, hidden width, index into ``features`` and the offsets
@@ -190,14 +195,14 @@ class Model:
                 packed[op["b2_off"]:op["b2_off"] + cp] = bb
                 continue
             w, b, gamma, beta, mu, var = p
-            scale = gamma / np.sqrt(var + np.float32(EFFNET_BN_EPS))  # eval-mode BatchNorm folded into the convolution
+            scale = gamma / np.sqrt(var + np.float32(self.bn_eps))  # eval-mode BatchNorm folded into the convolution
             w = w * scale[:, None, None, None]
             b = (b - mu) * scale + beta
             ks, cin, cout, cin_p, cout_p = op["ks"], op["cin"], op["cout"], op["cin_p"], op["cout_p"]
             if op["kind"] == 1:
-                if w.shape != (cin, 1, 3, 3):
-                    raise ValueError(f"depthwise parameter shape {w.shape} does not match width {cin}")
-                a = np.zeros((9, cin_p), np.float32); a[:, :cin] = w.reshape(cin, 9).T
+                if w.shape != (cin, 1, ks, ks):
+                    raise ValueError(f"depthwise parameter shape {w.shape} does not match width {cin}, kernel {ks}")
+                a = np.zeros((ks * ks, cin_p), np.float32); a[:, :cin] = w.reshape(cin, ks * ks).T
                 bb = np.zeros(cin_p, np.float32); bb[:cin] = b
                 packed[op["w_off"]:op["w_off"] + a.size] = a.ravel()
                 packed[op["b_off"]:op["b_off"] + cin_p] = bb

@@ -189,8 +189,8 @@ def effnet_parameters(seed: int, ops):
             w2 = (normal(i, 1, cin * sq) * np.float32(np.sqrt(1.0 / sq))).reshape(cin, sq, 1, 1)
             out.append((w1, np.float32(0.1) * normal(i, 2, sq), w2, np.float32(1.0) + np.float32(0.3) * normal(i, 3, cin)))
             continue
-        fan = 9 if op["kind"] == 1 else cin * ks * ks
-        shape = (cin, 1, 3, 3) if op["kind"] == 1 else (cout, cin, ks, ks)
+        fan = ks * ks if op["kind"] == 1 else cin * ks * ks
+        shape = (cin, 1, ks, ks) if op["kind"] == 1 else (cout, cin, ks, ks)
         n_out = shape[0]
         w = (normal(i, 0, int(np.prod(shape))) * np.float32(np.sqrt(2.0 / fan))).reshape(shape)
         u = [normal(i, 1 + k, n_out) for k in range(4)]

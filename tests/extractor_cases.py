@@ -85,7 +85,7 @@ def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=Fa
     got = device.to_host(m.extract_device(device.to_device(imgs), in_channels=3 if rgb else 1))
     assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
     for i in range(n_images):
-        ref = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std)
+        ref = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std, m.bn_eps)
         assert got[i].shape == ref.shape
         np.testing.assert_allclose(got[i], ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
     m.close()
@@ -156,7 +156,7 @@ def check_reference_surface(device, lib):
         np.testing.assert_allclose(fm, ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
     single = m.get_feature_maps(imgs[1])
     np.testing.assert_array_equal(single, maps[1])
-    for bad, exc in (("NoSuchNet", LookupError), ("EfficientNet_B4", NotImplementedError), ("DenseNet_201", NotImplementedError)):
+    for bad, exc in (("NoSuchNet", LookupError), ("DenseNet_201", NotImplementedError)):
         cfg = {"model": dict(CFG["model"], type=bad)}
         try:
             network.Model(cfg, 5, device=device, library=lib)

@@ -34,7 +34,7 @@ def test_emu_resnet50_layer1():
 
 
 @pytest.mark.parametrize("model,block,hw,rgb", [("EfficientNetV2_M", 2, (40, 36), False), ("EfficientNetV2_M", 5, (40, 32), False),
-                                                ("EfficientNetV2_S", 3, (34, 32), True)])
+                                                ("EfficientNetV2_S", 3, (34, 32), True), ("EfficientNet_B1", 4, (40, 32), False)])
 def test_emu_efficientnet_v2(model, block, hw, rgb):
     """EfficientNetV2 truncations under emulation: stem, FusedMBConv stages (3x3 expansion + 1x1 projection on the GEMM
     kernel, channel counts padded to 64), and with block 5 an MBConv stage (1x1 expansion, depthwise 3x3 / stride 2,

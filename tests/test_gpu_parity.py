@@ -261,7 +261,9 @@ def test_resnet50_extractor(torch_dev, lib, block, hw):
 
 
 @pytest.mark.parametrize("model,block,hw", [("EfficientNetV2_M", 4, (128, 96)), ("EfficientNetV2_M", 6, (512, 256)),
-                                            ("EfficientNetV2_S", 5, (96, 64)), ("EfficientNetV2_L", 5, (64, 64))])
+                                            ("EfficientNetV2_S", 5, (96, 64)), ("EfficientNetV2_L", 5, (64, 64)),
+                                            ("EfficientNet_B1", 5, (96, 64)), ("EfficientNet_B4", 6, (256, 128)),
+                                            ("EfficientNet_B7", 4, (64, 64))])
 def test_efficientnet_v2_extractor(torch_dev, lib, model, block, hw):
     """EfficientNetV2 truncations (the reference's run.toml default: EfficientNetV2_M, blocks 4 .. 6) - block 6 at the full
     512x256 print, [176, 32, 16] out - vs torch-CPU with the same seeded parameters."""
@@ -372,7 +374,7 @@ def test_run_driver_with_the_reference_default_model(tmp_path, capsys):
         m = network.Model(config, block)
         ops = m.effnet_ops()
         params = synth.effnet_parameters(1234, ops)
-        feats = lambda ims: [effnet_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), ops, params, m.mean, m.std)
+        feats = lambda ims: [effnet_oracle.get_feature_maps(clahe_oracle.clahe(im, 2.0, (8, 8)), ops, params, m.mean, m.std, m.bn_eps)
                              for im in ims]
         want += [int(r) for r in ncc_oracle.compare_maps(feats(queries), feats(gallery), matches, config)]
         m.close()
