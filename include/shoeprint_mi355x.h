@@ -298,6 +298,32 @@ int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, int64_t n, 
                        int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed, void* workspace,
                        float* out, spr_stream_t stream);
 
+/* ------------------------------------------------------------------ DenseNet_201 feature extractor
+ * network.py:176-179, :185-186: torchvision's densenet201 `features` = [conv0, norm0, relu0, pool0, denseblock1, transition1,
+ * denseblock2, transition2, denseblock3, transition3, denseblock4, norm5], truncated to features[:block], block in [1, 12].
+ * spr_densenet_op_info: int32[12] = kind {0 stem, 1 dense 1x1, 2 dense 3x3, 3 transition, 4 closing BatchNorm}, cin, cout,
+ * c_off, ctot, flags {stem: 1 BatchNorm folded, 2 ReLU, 4 max pool}, feature index, offsets in floats of w, b, s, t in the
+ * packed buffer, 0.  The caller writes the packed buffer (device, spr_densenet_packed_bytes):
+ *   stem        w [tap * 3 + c][64] (norm0 folded when flag 1), b [64]
+ *   dense 1x1   s, t [cin] = the BatchNorm in front of it as x * s + t (ReLU follows); w GEMM-packed [128/64][cin/16][64][16]
+ *               with the second BatchNorm folded, b [128]
+ *   dense 3x3   w GEMM-packed [1][9 * 128 / 16][64][16] (output channels 32 .. 63 zero), b [64] zeros
+ *   transition  s, t [cin]; w GEMM-packed [cout/64][cin/16][64][16], b [cout] zeros
+ *   closing     s, t [C]
+ * images / mean3 / inv_std3 / out as for spr_vgg16_forward. */
+typedef struct spr_densenet_plan spr_densenet_plan;
+int spr_densenet_plan_create(int32_t block, spr_densenet_plan** plan_out);
+void spr_densenet_plan_destroy(spr_densenet_plan* plan);
+int spr_densenet_num_ops(const spr_densenet_plan* plan);
+int spr_densenet_op_info(const spr_densenet_plan* plan, int32_t i, int32_t* info12);
+int spr_densenet_output_shape(const spr_densenet_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels, int32_t* out_h,
+                              int32_t* out_w);
+size_t spr_densenet_packed_bytes(const spr_densenet_plan* plan);
+size_t spr_densenet_workspace_bytes(const spr_densenet_plan* plan, int64_t n, int32_t in_h, int32_t in_w);
+int spr_densenet_forward(spr_densenet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                         int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed, void* workspace,
+                         float* out, spr_stream_t stream);
+
 /* ------------------------------------------------------------------ synthetic data
  * Bench/test support: the device twin of shoeprint_image_retrieval_amd/synth.py (bit-identical
  * float32 values).  out: device float32 [n, C, h, w]. */

@@ -77,6 +77,15 @@ SIGNATURES = {
                                     _VP, _VP, _VP, _VP]),
     "spr_vgg16_forward_taps": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                          _VP, _VP, _VP, _I32, C.POINTER(_I32), C.POINTER(_VP), _VP]),
+    "spr_densenet_plan_create": (C.c_int, [_I32, C.POINTER(_VP)]),
+    "spr_densenet_plan_destroy": (None, [_VP]),
+    "spr_densenet_num_ops": (C.c_int, [_VP]),
+    "spr_densenet_op_info": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),
+    "spr_densenet_output_shape": (C.c_int, [_VP, _I32, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "spr_densenet_packed_bytes": (_SZ, [_VP]),
+    "spr_densenet_workspace_bytes": (_SZ, [_VP, _I64, _I32, _I32]),
+    "spr_densenet_forward": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       _VP, _VP, _VP, _VP]),
     "spr_effnet_plan_create": (C.c_int, [_I32, _I32, C.POINTER(_VP)]),
     "spr_effnet_plan_destroy": (None, [_VP]),
     "spr_effnet_num_ops": (C.c_int, [_VP]),

@@ -69,7 +69,8 @@ rpack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __
 // grid = (tiles of 8x8 output pixels, images); out NHWC [n][Ho][Wo][64]
 __global__ void __launch_bounds__(kThreads)
 stem_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2, float s0,
-            float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias, float* __restrict__ out) {
+            float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias, float* __restrict__ out,
+            int relu) {
   constexpr int kT = 8, kP = 2 * kT + 5;  // 21 x 21 input patch
   __shared__ float patch[kP * kP * 3];
   __shared__ float wl[147 * 64];
@@ -115,13 +116,13 @@ stem_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, f
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int oy = oy0 + 2 * part + i / 8, ox = ox0 + i % 8;
-    if (oy < Ho && ox < Wo) out[((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + n] = fmaxf(acc[i], 0.0f);
+    if (oy < Ho && ox < Wo) out[((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + n] = relu ? fmaxf(acc[i], 0.0f) : acc[i];
   }
 }
 
 // ---------------------------------------------------------------- 3x3 / stride 2 / pad 1 max pool, NHWC
 __global__ void __launch_bounds__(kThreads)
-maxpool3_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, size_t total) {
+maxpool3_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, size_t total, int ldo) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
        i += static_cast<size_t>(gridDim.x) * kThreads) {
@@ -136,7 +137,7 @@ maxpool3_kernel(const float* __restrict__ in, int H, int W, int C, float* __rest
         const int y = 2 * oy + dy, x = 2 * ox + dx;
         if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, in[((img * H + y) * static_cast<size_t>(W) + x) * C + c]);
       }
-    out[i] = m;
+    out[(i / C) * ldo + c] = m;  // ldo: channel stride of the output tensor (>= C)
   }
 }
 
@@ -146,7 +147,11 @@ template <int KS, int STRIDE>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin, int cout, const float* __restrict__ wts,
                  const float* __restrict__ bias, const float* __restrict__ res, int relu, int nchw,
-                 float* __restrict__ out, const float* __restrict__ in_scale, int cout_real) {
+                 float* __restrict__ out, const float* __restrict__ in_scale, int cout_real, int lda, int ldc, int c_off,
+                 const float* __restrict__ pre_s, const float* __restrict__ pre_t) {
+  // lda / ldc: channel strides of the input / NHWC output tensors (>= cin / cout: a convolution may read a prefix of a wider
+  // tensor and write a channel range [c_off, c_off + cout_real) of one - DenseNet's concatenation); pre_s / pre_t: per input
+  // channel, max(x * s + t, 0) applied while the operand is loaded (BatchNorm + ReLU in FRONT of a 1x1 convolution), or null
   // relu: activation code (0 none, 1 ReLU, 2 SiLU); in_scale: [image][cin] factors on the input (squeeze-excitation), or null;
   // cout_real: channels of an NCHW result when cout is padded (0: all of them)
   __shared__ __attribute__((aligned(16))) float A[kGM * kGS];
@@ -185,7 +190,13 @@ conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin,
     const int y = py * STRIDE + dy - PAD, x = px * STRIDE + dx - PAD;
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pm_ok && y >= 0 && y < H && x >= 0 && x < W)
-      ra = *reinterpret_cast<const float4*>(in + ((pimg * H + y) * static_cast<size_t>(W) + x) * cin + cc * kGK + sq * 4);
+      ra = *reinterpret_cast<const float4*>(in + ((pimg * H + y) * static_cast<size_t>(W) + x) * lda + cc * kGK + sq * 4);
+    if (pre_s) {
+      const float4 ps = *reinterpret_cast<const float4*>(pre_s + cc * kGK + sq * 4);
+      const float4 pt = *reinterpret_cast<const float4*>(pre_t + cc * kGK + sq * 4);
+      ra.x = fmaxf(fmaf(ra.x, ps.x, pt.x), 0.f); ra.y = fmaxf(fmaf(ra.y, ps.y, pt.y), 0.f);
+      ra.z = fmaxf(fmaf(ra.z, ps.z, pt.z), 0.f); ra.w = fmaxf(fmaf(ra.w, ps.w, pt.w), 0.f);
+    }
     if (in_scale) {
       const float4 sc = *reinterpret_cast<const float4*>(in_scale + pimg * cin + cc * kGK + sq * 4);
       ra.x *= sc.x; ra.y *= sc.y; ra.z *= sc.z; ra.w *= sc.w;
@@ -228,8 +239,8 @@ conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin,
         const int ox = static_cast<int>(m % Wo), oy = static_cast<int>((m / Wo) % Ho);
         const size_t img = static_cast<size_t>(m / (static_cast<long long>(Wo) * Ho));
         out[((img * creal + ch) * Ho + oy) * static_cast<size_t>(Wo) + ox] = v;
-      } else {
-        out[static_cast<size_t>(m) * cout + ch] = v;
+      } else if (!cout_real || ch < cout_real) {
+        out[static_cast<size_t>(m) * ldc + c_off + ch] = v;
       }
     }
   }
@@ -316,6 +327,39 @@ enet_fc_kernel(const float* __restrict__ pooled, int C, int sq, const float* __r
     float s = b2[c];
     for (int j = 0; j < sq; ++j) s = fmaf(w2[static_cast<size_t>(c) * sq + j], hid[j], s);
     scale[img * C + c] = 1.0f / (1.0f + expf(-s));
+  }
+}
+
+// ================================================================ DenseNet building blocks (network.py:176-179)
+// 2x2 / stride 2 average pool (a transition's tail), NHWC [..][C] -> NHWC with channel stride ldo
+__global__ void __launch_bounds__(kThreads)
+dnet_avgpool_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, size_t total, int ldo) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C);
+    size_t p = i / C;
+    const int ox = static_cast<int>(p % Wo); p /= Wo;
+    const int oy = static_cast<int>(p % Ho);
+    const size_t img = p / Ho;
+    const float* b = in + ((img * H + 2 * oy) * static_cast<size_t>(W) + 2 * ox) * C + c;
+    out[(i / C) * ldo + c] = (b[0] + b[C] + b[static_cast<size_t>(W) * C] + b[static_cast<size_t>(W) * C + C]) * 0.25f;
+  }
+}
+
+// NHWC (channel stride ld, C channels) -> NCHW with an optional per-channel x * s + t (the closing BatchNorm) and ReLU
+__global__ void __launch_bounds__(kThreads)
+dnet_out_kernel(const float* __restrict__ in, int HW, int C, int ld, const float* __restrict__ sc, const float* __restrict__ sh,
+                int relu, float* __restrict__ out, size_t total) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int p = static_cast<int>(i % HW);
+    const int c = static_cast<int>((i / HW) % C);
+    const size_t img = i / (static_cast<size_t>(HW) * C);
+    float v = in[(img * HW + p) * ld + c];
+    if (sc) v = fmaf(v, sc[c], sh[c]);
+    if (relu) v = fmaxf(v, 0.0f);
+    out[i] = v;
   }
 }
 
@@ -438,7 +482,8 @@ static int launch_gemm(const RConv& c, const float* in, int64_t n, int h, int w,
   const long long m = static_cast<long long>(n) * ho * wo;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<KS, STRIDE>), dim3(static_cast<unsigned>((m + kGM - 1) / kGM),
                      static_cast<unsigned>(c.cout / kGN)), dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, c.cin, c.cout,
-                     pk + c.w_off, pk + c.b_off, res, c.relu, nchw, out, static_cast<const float*>(nullptr), 0);
+                     pk + c.w_off, pk + c.b_off, res, c.relu, nchw, out, static_cast<const float*>(nullptr), 0, c.cin, c.cout, 0,
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr));
   return check_launch("conv_gemm_kernel");
 }
 
@@ -464,13 +509,13 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
     const unsigned tiles = static_cast<unsigned>(ceil_div(h, 8) * ceil_div(w, 8));
     hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w,
                        in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + c.w_off,
-                       pk + c.b_off, buf[1]);
+                       pk + c.b_off, buf[1], 1);
     int rc = check_launch("stem_kernel");
     if (rc != SPR_OK) return rc;
     const int hp = (h + 1) / 2, wp = (w + 1) / 2;
     const size_t total = static_cast<size_t>(n) * hp * wp * 64;
     hipLaunchKernelGGL(maxpool3_kernel, dim3(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16))),
-                       dim3(kThreads), 0, s, buf[1], h, w, 64, buf[0], total);
+                       dim3(kThreads), 0, s, buf[1], h, w, 64, buf[0], total, 64);
     rc = check_launch("maxpool3_kernel");
     if (rc != SPR_OK) return rc;
     h = hp; w = wp;
@@ -704,7 +749,8 @@ static int launch_egemm(const EOp& o, const float* in, int64_t n, int h, int w, 
   const long long m = static_cast<long long>(n) * ho * wo;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<KS, STRIDE>), dim3(static_cast<unsigned>((m + kGM - 1) / kGM),
                      static_cast<unsigned>(o.cout_p / kGN)), dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, o.cin_p,
-                     o.cout_p, pk + o.w_off, pk + o.b_off, res, o.act, nchw, out, scale, o.cout);
+                     o.cout_p, pk + o.w_off, pk + o.b_off, res, o.act, nchw, out, scale, nchw ? o.cout : 0, o.cin_p, o.cout_p, 0,
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr));
   return check_launch("conv_gemm_kernel");
 }
 
@@ -783,4 +829,220 @@ extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, 
     }
   }
   return SPR_OK;
+}
+
+
+// ================================================================ DenseNet_201 truncations (network.py:176-179, :185-186)
+// torchvision's densenet201: features = [conv0, norm0, relu0, pool0, denseblock1, transition1, denseblock2, transition2,
+// denseblock3, transition3, denseblock4, norm5]; the reference keeps features[:block], block in [1, 12].  A dense layer is
+// BatchNorm + ReLU -> 1x1 convolution (128) -> BatchNorm + ReLU -> 3x3 convolution (32), concatenated behind its input: the
+// first BatchNorm + ReLU runs while the 1x1 convolution loads its operand (per-channel affine + ReLU), the second is folded
+// into that convolution, and the 3x3 convolution stores its 32 channels into the block's tensor at their offset.
+namespace {
+struct DOp {
+  int kind;     // 0 stem (7x7 / 2 convolution [+ BatchNorm] [+ ReLU] [+ 3x3 / 2 max pool]), 1 dense 1x1, 2 dense 3x3,
+                // 3 transition (BatchNorm + ReLU + 1x1 + 2x2 average pool), 4 closing BatchNorm
+  int cin, cout;
+  int c_off;    // dense 3x3: channel offset of its output in the block's tensor
+  int ctot;     // channels of the tensor this layer reads (kinds 1, 3, 4) or writes into (kind 2)
+  int flags;    // stem: 1 BatchNorm folded, 2 ReLU, 4 max pool
+  int feature;
+  size_t w_off, b_off, s_off, t_off;  // packed offsets (floats): weights, bias, pre-activation scale / shift
+};
+const int kDenseLayers[4] = {6, 12, 48, 32};
+}  // namespace
+
+struct spr_densenet_plan {
+  int block;
+  std::vector<DOp> ops;
+  size_t packed_floats;
+};
+
+extern "C" int spr_densenet_plan_create(int32_t block, spr_densenet_plan** plan_out) {
+  if (!plan_out) { set_error("spr_densenet_plan_create: null pointer"); return SPR_ERR_ARG; }
+  *plan_out = nullptr;
+  if (block < 1 || block > 12) { set_error("spr_densenet_plan_create: block %d: features[:block] with block in [1, 12]", block); return SPR_ERR_ARG; }
+  spr_densenet_plan* plan = new (std::nothrow) spr_densenet_plan();
+  if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
+  plan->block = block;
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off += (n + 3) / 4 * 4; return o; };
+  {
+    DOp o{};
+    o.kind = 0; o.cin = 3; o.cout = 64; o.feature = 0;
+    o.flags = (block >= 2 ? 1 : 0) | (block >= 3 ? 2 : 0) | (block >= 4 ? 4 : 0);
+    o.w_off = take(147 * 64); o.b_off = take(64);
+    plan->ops.push_back(o);
+  }
+  int c = 64;
+  for (int b = 0; b < 4 && 4 + 2 * b < block; ++b) {
+    const int ctot = c + 32 * kDenseLayers[b];
+    for (int l = 0; l < kDenseLayers[b]; ++l) {
+      DOp a{};
+      a.kind = 1; a.cin = c + 32 * l; a.cout = 128; a.ctot = ctot; a.feature = 4 + 2 * b;
+      a.s_off = take(a.cin); a.t_off = take(a.cin);
+      a.w_off = take(static_cast<size_t>(128) * a.cin); a.b_off = take(128);
+      plan->ops.push_back(a);
+      DOp d{};
+      d.kind = 2; d.cin = 128; d.cout = 32; d.c_off = c + 32 * l; d.ctot = ctot; d.feature = 4 + 2 * b;
+      d.w_off = take(static_cast<size_t>(64) * 128 * 9); d.b_off = take(64);  // output channels padded to the 64-wide tile
+      plan->ops.push_back(d);
+    }
+    c = ctot;
+    if (b < 3 && 5 + 2 * b < block) {
+      DOp t{};
+      t.kind = 3; t.cin = c; t.cout = c / 2; t.ctot = c; t.feature = 5 + 2 * b;
+      t.s_off = take(c); t.t_off = take(c);
+      t.w_off = take(static_cast<size_t>(c / 2) * c); t.b_off = take(c / 2);
+      plan->ops.push_back(t);
+      c /= 2;
+    }
+  }
+  if (block == 12) {
+    DOp n{};
+    n.kind = 4; n.cin = n.cout = c; n.ctot = c; n.feature = 11;
+    n.s_off = take(c); n.t_off = take(c);
+    plan->ops.push_back(n);
+  }
+  plan->packed_floats = off;
+  *plan_out = plan;
+  return SPR_OK;
+}
+
+extern "C" void spr_densenet_plan_destroy(spr_densenet_plan* plan) { delete plan; }
+extern "C" int spr_densenet_num_ops(const spr_densenet_plan* plan) { return plan ? static_cast<int>(plan->ops.size()) : SPR_ERR_ARG; }
+extern "C" size_t spr_densenet_packed_bytes(const spr_densenet_plan* plan) { return plan ? plan->packed_floats * sizeof(float) : 0; }
+
+// info[12] = kind, cin, cout, c_off, ctot, flags, feature, then the packed offsets (floats) w, b, s, t, then 0
+extern "C" int spr_densenet_op_info(const spr_densenet_plan* plan, int32_t i, int32_t* info) {
+  if (!plan || !info || i < 0 || i >= static_cast<int>(plan->ops.size())) { set_error("spr_densenet_op_info: bad argument"); return SPR_ERR_ARG; }
+  const DOp& o = plan->ops[i];
+  const int32_t v[12] = {o.kind, o.cin, o.cout, o.c_off, o.ctot, o.flags, o.feature, static_cast<int32_t>(o.w_off),
+                         static_cast<int32_t>(o.b_off), static_cast<int32_t>(o.s_off), static_cast<int32_t>(o.t_off), 0};
+  for (int k = 0; k < 12; ++k) info[k] = v[k];
+  return SPR_OK;
+}
+
+static void densenet_dims(const spr_densenet_plan* plan, int in_h, int in_w, int* c, int* h, int* w) {
+  int hh = (in_h + 1) / 2, ww = (in_w + 1) / 2, cc = 64;  // conv0: 7x7 s2 p3
+  if (plan->block >= 4) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; }
+  for (const DOp& o : plan->ops) {
+    if (o.kind == 2) cc = o.c_off + 32;
+    if (o.kind == 3) { hh /= 2; ww /= 2; cc = o.cout; }
+  }
+  *c = cc; *h = hh; *w = ww;
+}
+
+extern "C" int spr_densenet_output_shape(const spr_densenet_plan* plan, int32_t in_h, int32_t in_w, int32_t* channels,
+                                         int32_t* out_h, int32_t* out_w) {
+  if (!plan || !channels || !out_h || !out_w || in_h < 1 || in_w < 1) { set_error("spr_densenet_output_shape: bad argument"); return SPR_ERR_ARG; }
+  int c, h, w;
+  densenet_dims(plan, in_h, in_w, &c, &h, &w);
+  *channels = c; *out_h = h; *out_w = w;
+  return SPR_OK;
+}
+
+// three buffers as large as the largest tensor: the stem's output (64 channels at half resolution) or a block's tensor
+static size_t densenet_buf_floats(const spr_densenet_plan* plan, int64_t n, int in_h, int in_w) {
+  int hh = (in_h + 1) / 2, ww = (in_w + 1) / 2;
+  size_t best = static_cast<size_t>(n) * hh * ww * 64;
+  if (plan->block >= 4) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; }
+  for (const DOp& o : plan->ops) {
+    if (o.kind == 1 || o.kind == 3) {
+      const size_t f = static_cast<size_t>(n) * hh * ww * o.ctot;
+      if (f > best) best = f;
+    }
+    if (o.kind == 3) { hh /= 2; ww /= 2; }
+  }
+  return best;
+}
+extern "C" size_t spr_densenet_workspace_bytes(const spr_densenet_plan* plan, int64_t n, int32_t in_h, int32_t in_w) {
+  if (!plan || n < 0) return 0;
+  return 3 * align_up(densenet_buf_floats(plan, n, in_h, in_w) * sizeof(float), 256);
+}
+
+extern "C" int spr_densenet_forward(spr_densenet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
+                                    int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
+                                    void* workspace, float* out, spr_stream_t stream) {
+  if (!plan) { set_error("spr_densenet_forward: null plan"); return SPR_ERR_ARG; }
+  if (n < 0 || n > 65535 || in_h < 32 || in_w < 32 || (in_channels != 1 && in_channels != 3)) {
+    set_error("spr_densenet_forward: bad sizes (n in [0, 65535], images at least 32 x 32, in_channels 1 or 3)");
+    return SPR_ERR_ARG;
+  }
+  if (n == 0) return SPR_OK;
+  if (!images || !mean3 || !inv_std3 || !packed || !out || !workspace) { set_error("spr_densenet_forward: null pointer"); return SPR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* pk = static_cast<const float*>(packed);
+  const size_t buf_bytes = align_up(densenet_buf_floats(plan, n, in_h, in_w) * sizeof(float), 256);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  float* cat = reinterpret_cast<float*>(ws);                 // the current block's tensor (or the stem's output)
+  float* tmp = reinterpret_cast<float*>(ws + buf_bytes);     // a dense layer's 128-channel intermediate / a transition's output
+  float* nxt = reinterpret_cast<float*>(ws + 2 * buf_bytes); // the next block's tensor
+  auto blocks_of = [](size_t total) { return dim3(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16))); };
+  auto gemm = [&](int ks, const float* in, int h, int w, int cin, int cout_p, const DOp& o, int relu, float* dst, int cout_real,
+                  int lda, int ldc, int c_off, bool pre) {
+    const long long m = static_cast<long long>(n) * h * w;
+    const dim3 grid(static_cast<unsigned>((m + kGM - 1) / kGM), static_cast<unsigned>(cout_p / kGN));
+    const float* ps = pre ? pk + o.s_off : nullptr;
+    const float* pt = pre ? pk + o.t_off : nullptr;
+    if (ks == 3)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<3, 1>), grid, dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, cin,
+                         cout_p, pk + o.w_off, pk + o.b_off, static_cast<const float*>(nullptr), relu, 0, dst,
+                         static_cast<const float*>(nullptr), cout_real, lda, ldc, c_off, ps, pt);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm_kernel<1, 1>), grid, dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, cin,
+                         cout_p, pk + o.w_off, pk + o.b_off, static_cast<const float*>(nullptr), relu, 0, dst,
+                         static_cast<const float*>(nullptr), cout_real, lda, ldc, c_off, ps, pt);
+    return check_launch("conv_gemm_kernel");
+  };
+  int h = (in_h + 1) / 2, w = (in_w + 1) / 2, c = 64, ld = 64;
+  int rc = SPR_OK;
+  size_t i = 0;
+  {
+    const DOp& o = plan->ops[0];
+    // the width of the first block's tensor, if there is one: the pooled stem output goes straight into its first 64 channels
+    const int next_ld = plan->ops.size() > 1 && plan->ops[1].kind == 1 ? plan->ops[1].ctot : 64;
+    const unsigned tiles = static_cast<unsigned>(ceil_div(h, 8) * ceil_div(w, 8));
+    float* stem_out = (o.flags & 4) ? tmp : cat;
+    hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w, in_channels,
+                       mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + o.w_off, pk + o.b_off, stem_out,
+                       (o.flags & 2) ? 1 : 0);
+    rc = check_launch("stem_kernel");
+    if (rc != SPR_OK) return rc;
+    if (o.flags & 4) {
+      const int hp = (h + 1) / 2, wp = (w + 1) / 2;
+      const size_t total = static_cast<size_t>(n) * hp * wp * 64;
+      hipLaunchKernelGGL(maxpool3_kernel, blocks_of(total), dim3(kThreads), 0, s, tmp, h, w, 64, cat, total, next_ld);
+      rc = check_launch("maxpool3_kernel");
+      if (rc != SPR_OK) return rc;
+      h = hp; w = wp; ld = next_ld;
+    }
+    i = 1;
+  }
+  const float* fin_s = nullptr;
+  const float* fin_t = nullptr;
+  for (; i < plan->ops.size(); ++i) {
+    const DOp& o = plan->ops[i];
+    if (o.kind == 1) {          // BatchNorm + ReLU (operand load) -> 1x1 -> BatchNorm (folded) + ReLU
+      rc = gemm(1, cat, h, w, o.cin, 128, o, 1, tmp, 0, o.ctot, 128, 0, true);
+    } else if (o.kind == 2) {   // 3x3, its 32 channels behind the layer's input
+      rc = gemm(3, tmp, h, w, 128, 64, o, 0, cat, 32, 128, o.ctot, o.c_off, false);
+      c = o.c_off + 32; ld = o.ctot;
+    } else if (o.kind == 3) {   // BatchNorm + ReLU -> 1x1 -> 2x2 average pool into the next block's tensor
+      rc = gemm(1, cat, h, w, o.cin, o.cout, o, 0, tmp, 0, o.ctot, o.cout, 0, true);
+      if (rc != SPR_OK) return rc;
+      const int next_ld = i + 1 < plan->ops.size() && plan->ops[i + 1].kind == 1 ? plan->ops[i + 1].ctot : o.cout;
+      const size_t total = static_cast<size_t>(n) * (h / 2) * (w / 2) * o.cout;
+      hipLaunchKernelGGL(dnet_avgpool_kernel, blocks_of(total), dim3(kThreads), 0, s, tmp, h, w, o.cout, nxt, total, next_ld);
+      rc = check_launch("dnet_avgpool_kernel");
+      float* old = cat; cat = nxt; nxt = old;
+      h /= 2; w /= 2; c = o.cout; ld = next_ld;
+    } else {                    // the closing BatchNorm rides on the layout change below
+      fin_s = pk + o.s_off; fin_t = pk + o.t_off;
+    }
+    if (rc != SPR_OK) return rc;
+  }
+  const size_t total = static_cast<size_t>(n) * c * h * w;
+  hipLaunchKernelGGL(dnet_out_kernel, blocks_of(total), dim3(kThreads), 0, s, cat, h * w, c, ld, fin_s, fin_t, 0, out, total);
+  return check_launch("dnet_out_kernel");
 }

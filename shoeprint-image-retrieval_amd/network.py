@@ -13,8 +13,8 @@ image per launch (network.py:228) — runs whole batches; ``extract_device`` kee
 for the scorer.  Unknown ``model.type`` raises ``LookupError("Model string not found")`` as the
 reference does (network.py:180-182).  ``EfficientNetV2_S / _M / _L`` (network.py:163-175; run.toml's default) and
 ``EfficientNet_B1 .. B5, B7`` (network.py:139-162) run on ``spr_effnet_forward`` (stem, FusedMBConv and MBConv stages;
-BatchNorm folded and parameters packed here); the reference's DenseNet_201 is not built and raises
-``NotImplementedError``.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
+BatchNorm folded and parameters packed here) and ``DenseNet_201`` (network.py:176-179) on ``spr_densenet_forward``: every
+backbone of the reference's list is built.  ``model.type = "ResNet50"`` is BUILD-DEFINED (BASELINE.json config 3 names a ResNet50
 layer3 extractor, the reference has none): torchvision's resnet50 cut after ``block`` of its top-level children
 [conv1, bn1, relu, maxpool, layer1, layer2, layer3], block = 5 / 6 / 7, ImageNet mean / std.
 
@@ -79,6 +79,30 @@ def effnet_state_names(ops) -> list[tuple[str, str]]:
     return names
 
 
+def densenet_state_names(ops) -> list[tuple]:
+    """Module names of the layers in a torchvision densenet201 state dict, in ``Model.densenet_ops`` order (written from
+    torchvision's module layout; not checked against a checkpoint: none is available offline)."""
+    names, layer = [], {}
+    for op in ops:
+        f = op["feature"]
+        if op["kind"] == 0:
+            names.append(("features.conv0", "features.norm0"))
+        elif op["kind"] == 1:
+            b = (f - 4) // 2 + 1
+            pre = f"features.denseblock{b}.denselayer{layer.setdefault(b, 0) + 1}"
+            names.append((f"{pre}.norm1", f"{pre}.conv1", f"{pre}.norm2"))
+        elif op["kind"] == 2:
+            b = (f - 4) // 2 + 1
+            names.append((f"features.denseblock{b}.denselayer{layer[b] + 1}.conv2",))
+            layer[b] += 1
+        elif op["kind"] == 3:
+            b = (f - 5) // 2 + 1
+            names.append((f"features.transition{b}.norm", f"features.transition{b}.conv"))
+        else:
+            names.append(("features.norm5",))
+    return names
+
+
 class Model:
     """Operate on the truncated VGG16 and its pre-processing (reference network.py:90-269)."""
 
@@ -91,7 +115,8 @@ class Model:
         model_str = model_cfg["type"]
         self.resnet = model_str in _RESNET_MODELS
         self.effnet = model_str in _EFFNET_MODELS
-        if model_str not in _VGG_MODELS and not self.resnet and not self.effnet:
+        self.densenet = model_str == "DenseNet_201"
+        if model_str not in _VGG_MODELS and not self.resnet and not self.effnet and not self.densenet:
             if model_str in _REFERENCE_MODELS:
                 raise NotImplementedError(f"backbone {model_str} is not built on MI355X yet (SURVEY §8 f4); "
                                           f"use one of {sorted(_VGG_MODELS) + sorted(_EFFNET_MODELS)}")
@@ -101,6 +126,8 @@ class Model:
             self.arch, (self.mean, self.std) = -1, _RESNET_MODELS[model_str]
         elif self.effnet:
             self.arch, self.mean, self.std, self.bn_eps = _EFFNET_MODELS[model_str]
+        elif self.densenet:
+            self.arch, self.mean, self.std, self.bn_eps = -2, IMAGENET_MEAN, IMAGENET_STD, 1e-5
         else:
             self.arch, self.mean, self.std = _VGG_MODELS[model_str]
         self.block = int(block)
@@ -112,6 +139,14 @@ class Model:
             device = TorchDevice()
         self.dev = device
         handle = C.c_void_p()
+        if self.densenet:
+            self.lib.check(self.lib.spr_densenet_plan_create(self.block, C.byref(handle)))
+            self.handle = handle
+            self.n_convs = self.lib.spr_densenet_num_ops(handle)
+            if parameters is None:
+                parameters = self._load_densenet_parameters(config)
+            self._set_densenet_parameters(parameters)
+            return
         if self.effnet:
             self.lib.check(self.lib.spr_effnet_plan_create(self.arch, self.block, C.byref(handle)))
             self.handle = handle
@@ -216,6 +251,102 @@ class Model:
             bb = np.zeros(cout_p, np.float32); bb[:cout] = b
             packed[op["w_off"]:op["w_off"] + wp.size] = np.ascontiguousarray(wp).ravel()
             packed[op["b_off"]:op["b_off"] + cout_p] = bb
+        self.packed = self.dev.to_device(packed)
+
+    # ------------------------------------------------------------------ DenseNet_201 (network.py:176-179)
+    def densenet_ops(self) -> list[dict]:
+        """The layers of features[:block]: kind (0 stem, 1 dense 1x1, 2 dense 3x3, 3 transition, 4 closing BatchNorm), widths,
+        channel offset / width of the block tensor, stem flags, index into ``features`` and packed offsets (floats)."""
+        keys = ("kind", "cin", "cout", "c_off", "ctot", "flags", "feature", "w_off", "b_off", "s_off", "t_off")
+        out = []
+        for i in range(self.n_convs):
+            info = (C.c_int32 * 12)()
+            self.lib.check(self.lib.spr_densenet_op_info(self.handle, i, info))
+            out.append(dict(zip(keys, list(info))))
+        return out
+
+    def _load_densenet_parameters(self, config):
+        global _warned
+        path = config.get("mi355x", {}).get("weights", "")
+        ops = self.densenet_ops()
+        if path:
+            import torch
+
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            bn = lambda m: tuple(state[f"{m}.{n}"].float().numpy() for n in ("weight", "bias", "running_mean", "running_var"))
+            wt = lambda m: state[f"{m}.weight"].float().numpy()
+            params = []
+            for op, names in zip(ops, densenet_state_names(ops)):
+                if op["kind"] == 0:
+                    params.append((wt(names[0]),) + bn(names[1]))
+                elif op["kind"] == 1:
+                    params.append(bn(names[0]) + (wt(names[1]),) + bn(names[2]))
+                elif op["kind"] == 2:
+                    params.append((wt(names[0]),))
+                elif op["kind"] == 3:
+                    params.append(bn(names[0]) + (wt(names[1]),))
+                else:
+                    params.append(bn(names[0]))
+            return params
+        if not _warned:
+            print(f"shoeprint_image_retrieval_amd: no [mi355x].weights given — using seeded synthetic {self.model_str} "
+                  "weights (pretrained ImageNet weights cannot be downloaded offline)", file=sys.stderr)
+            _warned = True
+        return synth.densenet_parameters(1234, ops)
+
+    def _set_densenet_parameters(self, parameters):
+        ops = self.densenet_ops()
+        if len(parameters) < len(ops):
+            raise ValueError(f"{len(ops)} layers need parameters, got {len(parameters)}")
+        eps = np.float32(self.bn_eps)
+        packed = np.zeros(self.lib.spr_densenet_packed_bytes(self.handle) // 4, np.float32)
+
+        def affine(gamma, beta, mu, var):  # eval-mode BatchNorm as x * s + t
+            s = gamma / np.sqrt(var + eps)
+            return s, beta - mu * s
+
+        def gemm_pack(w, cout_p):  # [cout][cin][k][k] -> [cout_p/64][K/16][64][16], K index = tap * cin + c
+            cout, cin, k, _ = w.shape
+            wp = np.zeros((cout_p, k * k, cin), np.float32)
+            wp[:cout] = w.reshape(cout, cin, k * k).transpose(0, 2, 1)
+            return np.ascontiguousarray(wp.reshape(cout_p // 64, 64, k * k * cin // 16, 16).transpose(0, 2, 1, 3)).ravel()
+
+        def put(off, a):
+            a = np.asarray(a, np.float32).ravel()
+            packed[off:off + a.size] = a
+
+        for op, p in zip(ops, parameters):
+            p = [np.asarray(t, dtype=np.float32) for t in p]
+            if op["kind"] == 0:
+                w, b = p[0], np.zeros(64, np.float32)
+                if w.shape != (64, 3, 7, 7):
+                    raise ValueError(f"conv0 parameter shape {w.shape}")
+                if op["flags"] & 1:
+                    s, t = affine(*p[1:5])
+                    w, b = w * s[:, None, None, None], t
+                put(op["w_off"], w.reshape(64, 3, 49).transpose(2, 1, 0))  # [tap][c][n]
+                put(op["b_off"], b)
+            elif op["kind"] == 1:
+                s1, t1 = affine(*p[0:4])
+                s2, t2 = affine(*p[5:9])
+                w = p[4]
+                if w.shape != (128, op["cin"], 1, 1):
+                    raise ValueError(f"dense 1x1 parameter shape {w.shape} for {op['cin']} input channels")
+                put(op["s_off"], s1); put(op["t_off"], t1)
+                put(op["w_off"], gemm_pack(w * s2[:, None, None, None], 128)); put(op["b_off"], t2)
+            elif op["kind"] == 2:
+                if p[0].shape != (32, 128, 3, 3):
+                    raise ValueError(f"dense 3x3 parameter shape {p[0].shape}")
+                put(op["w_off"], gemm_pack(p[0], 64))
+            elif op["kind"] == 3:
+                s, t = affine(*p[0:4])
+                if p[4].shape != (op["cout"], op["cin"], 1, 1):
+                    raise ValueError(f"transition parameter shape {p[4].shape}")
+                put(op["s_off"], s); put(op["t_off"], t)
+                put(op["w_off"], gemm_pack(p[4], op["cout"]))
+            else:
+                s, t = affine(*p[0:4])
+                put(op["s_off"], s); put(op["t_off"], t)
         self.packed = self.dev.to_device(packed)
 
     # ------------------------------------------------------------------ ResNet50 (build-defined)
@@ -352,7 +483,7 @@ class Model:
     # ------------------------------------------------------------------ shapes
     def output_shape(self, in_h: int, in_w: int) -> tuple[int, int, int]:
         c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
-        fn = (self.lib.spr_effnet_output_shape if self.effnet else
+        fn = (self.lib.spr_densenet_output_shape if self.densenet else self.lib.spr_effnet_output_shape if self.effnet else
               self.lib.spr_resnet_output_shape if self.resnet else self.lib.spr_vgg16_output_shape)
         self.lib.check(fn(self.handle, in_h, in_w, C.byref(c), C.byref(h), C.byref(w)))
         return c.value, h.value, w.value
@@ -365,9 +496,9 @@ class Model:
         n, h, w = shape[0], shape[1], shape[2]
         c, oh, ow = self.output_shape(h, w)
         out = dev.empty((n, c, oh, ow), np.float32)
-        ws_fn = (self.lib.spr_effnet_workspace_bytes if self.effnet else
+        ws_fn = (self.lib.spr_densenet_workspace_bytes if self.densenet else self.lib.spr_effnet_workspace_bytes if self.effnet else
                  self.lib.spr_resnet_workspace_bytes if self.resnet else self.lib.spr_vgg16_workspace_bytes)
-        fwd = (self.lib.spr_effnet_forward if self.effnet else
+        fwd = (self.lib.spr_densenet_forward if self.densenet else self.lib.spr_effnet_forward if self.effnet else
                self.lib.spr_resnet_forward if self.resnet else self.lib.spr_vgg16_forward)
         ws = dev.empty_bytes(max(16, ws_fn(self.handle, n, h, w)))
         mean = (C.c_float * 3)(*self.mean)
@@ -381,7 +512,7 @@ class Model:
         ``model.features`` like ``block``, each just behind a ReLU (16 = conv3_3, 23 = conv4_3, 30 = conv5_3 for VGG16) -
         as float32 device arrays [N, C_l, h_l, w_l], in that order; a tap equal to ``block`` is the network's output.
         Multi-layer scoring (BASELINE config 5) feeds on this: the reference would run the extractor once per block."""
-        if self.resnet or self.effnet:
+        if self.resnet or self.effnet or self.densenet:
             raise NotImplementedError("feature taps are built for the plain VGG backbones")
         dev = self.dev
         n, h, w = dev.shape(images_dev)[:3]
@@ -488,7 +619,8 @@ class Model:
 
     def close(self):
         if getattr(self, "handle", None):
-            (self.lib.spr_effnet_plan_destroy if getattr(self, "effnet", False) else
+            (self.lib.spr_densenet_plan_destroy if getattr(self, "densenet", False) else
+             self.lib.spr_effnet_plan_destroy if getattr(self, "effnet", False) else
              self.lib.spr_resnet_plan_destroy if self.resnet else self.lib.spr_vgg16_plan_destroy)(self.handle)
             self.handle = None
 

@@ -202,6 +202,36 @@ def effnet_parameters(seed: int, ops):
     return out
 
 
+def densenet_parameters(seed: int, ops):
+    """Seeded parameters of a DenseNet_201 truncation (``Model.densenet_ops``), in torchvision's module order per layer:
+    stem (conv0 weight, norm0 gamma, beta, mean, variance); dense 1x1 (norm1 x4, conv1 weight, norm2 x4); dense 3x3 (conv2
+    weight); transition (norm x4, conv weight); closing BatchNorm (x4)."""
+    def normal(i, k, n):
+        return irwin_hall_int(stream_key(seed, STREAM_WEIGHT, 13000 + 16 * i + k), np.arange(n, dtype=np.int64)).astype(np.float32) / np.float32(37837.0)
+
+    def bn(i, k, n):
+        u = [normal(i, k + j, n) for j in range(4)]
+        return (np.float32(1.0) + np.float32(0.1) * np.clip(u[0], -3, 3), np.float32(0.05) * u[1], np.float32(0.1) * u[2],
+                np.float32(1.0) + np.float32(0.4) * np.tanh(u[3]))
+
+    def conv(i, k, cout, cin, ks):
+        return (normal(i, k, cout * cin * ks * ks) * np.float32(np.sqrt(2.0 / (cin * ks * ks)))).reshape(cout, cin, ks, ks)
+
+    out = []
+    for i, op in enumerate(ops):
+        if op["kind"] == 0:
+            out.append((conv(i, 0, 64, 3, 7),) + bn(i, 1, 64))
+        elif op["kind"] == 1:
+            out.append(bn(i, 0, op["cin"]) + (conv(i, 4, 128, op["cin"], 1),) + bn(i, 5, 128))
+        elif op["kind"] == 2:
+            out.append((conv(i, 0, 32, 128, 3),))
+        elif op["kind"] == 3:
+            out.append(bn(i, 0, op["cin"]) + (conv(i, 4, op["cout"], op["cin"], 1),))
+        else:
+            out.append(bn(i, 0, op["cin"]))
+    return [tuple(np.ascontiguousarray(t, dtype=np.float32) for t in p) for p in out]
+
+
 def bfloat16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bfloat16 bit patterns (uint16), round to nearest even — the storage form the scorer
     accepts for bf16 features (numpy has no bfloat16 type)."""

@@ -91,6 +91,26 @@ def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=Fa
     m.close()
 
 
+def check_densenet(block, hw, device, lib, n_images=2, tol=5e-5):
+    """DenseNet_201 features[:block] against the torch-CPU oracle with the same seeded parameters; parity unpinned."""
+    from oracle import densenet_oracle
+
+    cfg = {"model": dict(CFG["model"], type="DenseNet_201"), "comparison": CFG["comparison"]}
+    m = network.Model(cfg, block, device=device, library=lib)
+    ops = m.densenet_ops()
+    params = synth.densenet_parameters(1234, ops)
+    names = network.densenet_state_names(ops)
+    assert len(names) == len(ops) and names[0] == ("features.conv0", "features.norm0")
+    imgs = np.stack([synth.shoeprint_image(8, i, *hw) for i in range(n_images)])
+    got = device.to_host(m.extract_device(device.to_device(imgs)))
+    assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    for i in range(n_images):
+        ref = densenet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std)
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+    m.close()
+
+
 def check_multi_layer_pipeline(device, lib, scorer, hw=(64, 48), taps=(9, 14, 16), n_gallery=7, n_queries=3, batch=3):
     """BASELINE config 5 in miniature: one extractor pass with feature taps, per-layer scoring chains on their own
     streams (gallery in batches, the last one ragged), fusion on the device - against the oracle chain: torch-CPU features
@@ -156,7 +176,7 @@ def check_reference_surface(device, lib):
         np.testing.assert_allclose(fm, ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
     single = m.get_feature_maps(imgs[1])
     np.testing.assert_array_equal(single, maps[1])
-    for bad, exc in (("NoSuchNet", LookupError), ("DenseNet_201", NotImplementedError)):
+    for bad, exc in (("NoSuchNet", LookupError),):
         cfg = {"model": dict(CFG["model"], type=bad)}
         try:
             network.Model(cfg, 5, device=device, library=lib)

@@ -42,6 +42,14 @@ def test_emu_efficientnet_v2(model, block, hw, rgb):
     ec.check_effnet(model, block, hw, HostDevice(), emu_library(), n_images=1, rgb=rgb)
 
 
+@pytest.mark.parametrize("block,hw", [(1, (34, 32)), (3, (34, 32)), (5, (40, 36)), (6, (36, 40))])
+def test_emu_densenet201(block, hw):
+    """DenseNet_201 truncations under emulation: the stem with and without norm0 / relu0 / pool0, the first dense block
+    (BatchNorm + ReLU on the operand load of the 1x1 convolutions, 3x3 outputs stored into their channel range of the block
+    tensor), a transition (average pool into the next block's tensor)."""
+    ec.check_densenet(block, hw, HostDevice(), emu_library(), n_images=1)
+
+
 def test_emu_multi_layer_pipeline():
     ec.check_multi_layer_pipeline(HostDevice(), emu_library(), emu_scorer("fft"), hw=(40, 32), n_gallery=5, n_queries=2, batch=2)
 

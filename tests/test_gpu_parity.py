@@ -272,6 +272,15 @@ def test_efficientnet_v2_extractor(torch_dev, lib, model, block, hw):
     ec.check_effnet(model, block, hw, torch_dev, lib, n_images=1 if hw[0] >= 512 else 2, tol=1e-4)
 
 
+@pytest.mark.parametrize("block,hw", [(4, (64, 48)), (7, (96, 64)), (9, (128, 96)), (12, (512, 256))])
+def test_densenet201_extractor(torch_dev, lib, block, hw):
+    """DenseNet_201 truncations - block 12 (all of `features`, [1920, 16, 8] out) at the full 512x256 print - vs torch-CPU
+    with the same seeded parameters."""
+    import extractor_cases as ec
+
+    ec.check_densenet(block, hw, torch_dev, lib, n_images=1 if hw[0] >= 512 else 2, tol=1e-4)
+
+
 def test_multi_layer_pipeline(torch_dev, lib, fft_scorer):
     """Config 5: conv3_3 + conv4_3 + conv5_3 taps of one VGG16 pass, scored on separate streams, fused on the device."""
     import extractor_cases as ec
