@@ -1,4 +1,6 @@
-// ResNet50 feature extractor through layer1 / layer2 / layer3 (BASELINE.json config 3: "ResNet50 layer3 summed maps").
+// Feature extractors on the implicit-GEMM convolution kernel of this file: ResNet50 through layer1 / layer2 / layer3
+// (BASELINE.json config 3: "ResNet50 layer3 summed maps"; first part), the EfficientNet B-series and V2 truncations
+// (network.py:139-175; spr_effnet_*, second part) and DenseNet_201 (network.py:176-179; spr_densenet_*, third part).
 //
 // The reference has no ResNet (network.py:121-182 lists VGG, EfficientNet and DenseNet) and its truncation
 // `list(model.features.children())[:block]` (network.py:185) would not apply to torchvision's resnet50, which has no
