@@ -99,6 +99,19 @@ __device__ __forceinline__ unsigned bf16_round(float v) {  // round to nearest e
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float bf16_value(unsigned bits) { return __uint_as_float(bits << 16); }
+// a float as the plan's 16-bit storage type (bit pattern) and back
+__device__ __forceinline__ unsigned to_storage(float v, int dtype) {
+  if (dtype == SPR_BF16) return bf16_round(v);
+  union { _Float16 h; uint16_t u; } c;
+  c.h = static_cast<_Float16>(v);
+  return c.u;
+}
+__device__ __forceinline__ float from_storage(unsigned bits, int dtype) {
+  if (dtype == SPR_BF16) return bf16_value(bits);
+  union { _Float16 h; uint16_t u; } c;
+  c.u = static_cast<uint16_t>(bits);
+  return static_cast<float>(c.h);
+}
 
 // ---- preparation: grid = (channels, items) ---------------------------------------------------------------------------
 // EXACT form: the search map enters the matrix cores RAW (bf16 as stored: one MFMA per tile step, every product exact) and
@@ -128,6 +141,26 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
     else
       build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
   };
+  // Conditioning.  The raw operands make  num = R - corrections  a difference of numbers (mean / sigma)^2 times larger than
+  // num (measured: 4e-4 on scores of maps offset by 100 sigma).  A channel whose values all sit near its mean - the only way
+  // to have a large mean / sigma - can be shifted EXACTLY in its storage type: kappa = the mean rounded to the storage type,
+  // x - kappa representable for every pixel (checked here, pixel by pixel).  Then x - kappa enters the matrix cores and
+  // mean - kappa the corrections: the same algebra, exact products as before, and the cancellation is gone.  Channels spread
+  // over several binades fail the check and stay as they are: their mean / sigma is small.
+  auto exact_shift = [&](size_t base, int raw_w, float mean) {  // returns kappa (0: no exact shift exists)
+    const float kappa = from_storage(to_storage(mean, g.dtype), g.dtype);
+    double bad = 0.0;
+    for (int i = tid; i < M::NPOS; i += wg_size()) {
+      const int y = i / M::TW, x = i - y * M::TW;
+      const float d = from_storage(raw[base + static_cast<size_t>(y + g.crop) * raw_w + (x + g.crop)], g.dtype) - kappa;
+      if (from_storage(to_storage(d, g.dtype), g.dtype) != d) bad += 1.0;
+    }
+    return block_sum(bad, red) == 0.0 ? kappa : 0.0f;
+  };
+  auto shifted_bits = [&](size_t idx, float kappa) -> unsigned {
+    const unsigned bits = raw[idx];
+    return kappa == 0.0f ? bits : to_storage(from_storage(bits, g.dtype) - kappa, g.dtype);
+  };
   // the channel columns that pad U / V to a multiple of 16 are zero: the last channel's workgroup writes them
   auto store_column = [&](float* mat, int pos, float v) {
     mat[static_cast<size_t>(pos) * cp + c] = v;
@@ -139,16 +172,18 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
     float mean;
     load_centred(maps, base, g.q_w, g.crop, M::TH, M::TW, g.dtype, x0, red, &mean);
     const float scale = template_scale(x0, M::NPOS, red);
-    // template rows as stored (bfloat16 bit patterns), padded to 16 taps
+    const float kappa = exact_shift(base, g.q_w, mean);
+    // template rows in the storage type (as stored, or shifted by kappa), padded to 16 taps
     uint16_t* rows = reinterpret_cast<uint16_t*>(out_item + static_cast<size_t>(c) * M::kQMapBytes);
     for (int i = tid; i < M::TH * 16; i += wg_size()) {
       const int u = i >> 4, v = i & 15;
-      rows[i] = v < M::TW ? raw[base + static_cast<size_t>(u + g.crop) * g.q_w + (v + g.crop)] : static_cast<uint16_t>(0);
+      rows[i] = v < M::TW ? static_cast<uint16_t>(shifted_bits(base + static_cast<size_t>(u + g.crop) * g.q_w + (v + g.crop), kappa))
+                          : static_cast<uint16_t>(0);
     }
     float* sc = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kQMapBytes);
     if (tid == 0) {
       sc[2 * c] = scale;
-      sc[2 * c + 1] = scale * mean;
+      sc[2 * c + 1] = scale * (mean - kappa);
     }
     if constexpr (EXACT) {
       float* U = sc + 2 * g.channels;
@@ -167,13 +202,15 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
     const size_t base = (item * g.channels + c) * static_cast<size_t>(g.g_h) * g.g_w;
     float mean;
     load_centred(maps, base, g.g_w, g.crop, M::TH, M::TW, g.dtype, x0, red, &mean);
+    const float kappa = EXACT ? exact_shift(base, g.g_w, mean) : 0.0f;
+    if constexpr (EXACT) mean -= kappa;  // from here on: the mean of the map as the matrix cores see it
     float* eb = reinterpret_cast<float*>(out_item + static_cast<size_t>(c) * M::kGChanBytes);
     float* ebs = eb + M::NPOS;
     unsigned* hl = reinterpret_cast<unsigned*>(ebs + M::NPOS);
     for (int i = tid; i < M::NPOS; i += wg_size()) {
       if constexpr (EXACT) {
         const int y = i / M::TW, x = i - y * M::TW;
-        hl[i] = static_cast<unsigned>(raw[base + static_cast<size_t>(y + g.crop) * g.g_w + (x + g.crop)]) << 16;
+        hl[i] = shifted_bits(base + static_cast<size_t>(y + g.crop) * g.g_w + (x + g.crop), kappa) << 16;
       } else {
         const float v = x0[i];
         const unsigned hi = bf16_round(v);

@@ -208,6 +208,27 @@ def check_mfma_method_fp16(make_scorer, channels, nq, ng, tol=TIGHT):
     np.testing.assert_allclose(got, ref, atol=tol, rtol=0)
 
 
+def check_mfma_conditioning(make_scorer, channels=6, nq=3, ng=3, tol=TIGHT):
+    """Maps riding on a large offset (mean / sigma up to ~1000): with the raw operands on the matrix cores the numerator
+    would be a difference of numbers (mean / sigma)^2 times its size (4e-4 on the scores at an offset of 100, 5e-2 at 1000,
+    before the prep kernels shifted such channels exactly in their storage type); channels spread over several binades (offset
+    0) take the other branch.  Both forms of the method and both storage types."""
+    for offset in (0.0, 3.0, 100.0, 1000.0):
+        g = [np.maximum(synth.gallery_features(41, i, channels, 32, 16), 0) + np.float32(offset) for i in range(ng)]
+        q = [np.maximum(synth.query_features(41, i, i, channels, 32, 16), 0) + np.float32(offset) for i in range(nq)]
+        qb, gb = synth.bfloat16_bits(np.stack(q)), synth.bfloat16_bits(np.stack(g))
+        ref = oracle.similarity_matrix(list(synth.from_bfloat16_bits(qb)), list(synth.from_bfloat16_bits(gb)), precise=True)
+        sc = make_scorer("mfma")
+        dev = sc.dev
+        got = dev.to_host(sc.scores_device(dev.to_device(qb), dev.to_device(gb)))
+        np.testing.assert_allclose(got, ref, atol=tol, rtol=0, err_msg=f"bfloat16, offset {offset}")
+        if offset <= 100.0:  # (float16 keeps 11 bits: an offset of 1000 leaves steps of 0.5 - still a valid map, same rule)
+            q16, g16 = np.stack(q).astype(np.float16), np.stack(g).astype(np.float16)
+            ref16 = oracle.similarity_matrix(list(q16.astype(np.float32)), list(g16.astype(np.float32)), precise=True)
+            got16 = dev.to_host(sc.scores_device(dev.to_device(q16), dev.to_device(g16)))
+            np.testing.assert_allclose(got16, ref16, atol=tol, rtol=0, err_msg=f"float16, offset {offset}")
+
+
 def check_mfma_large_gallery(make_scorer, monkeypatch, channels, nq, ng, oracle_pairs=12):
     qb, gb, qf, gf = _bf16_sets(47, channels, nq, ng)
     mf, ff = make_scorer("mfma"), make_scorer("fft")

@@ -181,6 +181,12 @@ def test_emu_matrix_core_method_fp16():
     pc.check_mfma_method_fp16(emu_scorer, 3, 18, 2)
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
+def test_emu_matrix_core_method_conditioning(monkeypatch, exact):
+    monkeypatch.setenv("SPR_NCC_MFMA_EXACT", exact)
+    pc.check_mfma_conditioning(emu_scorer)
+
+
 def test_emu_matrix_core_method_split_form(monkeypatch):
     """SPR_NCC_MFMA_EXACT=0: the centred search map as hi + lo on the matrix cores instead of the raw map + correction matrix."""
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")

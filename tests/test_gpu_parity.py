@@ -94,6 +94,12 @@ def test_matrix_core_method_fp16(lib):
     pc.check_mfma_method_fp16(_make_scorer(lib), 512, 70, 4)
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
+def test_matrix_core_method_conditioning(lib, monkeypatch, exact):
+    monkeypatch.setenv("SPR_NCC_MFMA_EXACT", exact)
+    pc.check_mfma_conditioning(_make_scorer(lib), channels=64)
+
+
 def test_matrix_core_method_split_form(lib, monkeypatch):
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")
     pc.check_mfma_method(_make_scorer(lib), 256, 70, 3)
