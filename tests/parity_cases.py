@@ -229,6 +229,26 @@ def check_mfma_conditioning(make_scorer, channels=6, nq=3, ng=3, tol=TIGHT):
             np.testing.assert_allclose(got16, ref16, atol=tol, rtol=0, err_msg=f"float16, offset {offset}")
 
 
+def check_mfma_degenerate_channels(make_scorer, tol=TIGHT):
+    """All-zero, constant and single-spike channels on either side (similarity.py:65-70: they contribute 0, or what little
+    the spike correlates) through the matrix-core method: finite, equal to the oracle."""
+    c, nq, ng = 6, 2, 2
+    g = [np.maximum(synth.gallery_features(41, i, c, 32, 16), 0) for i in range(ng)]
+    q = [np.maximum(synth.query_features(41, i, i, c, 32, 16), 0) for i in range(nq)]
+    g[0][1] = 0.0
+    q[1][2] = 0.0
+    g[1][3] = 7.0
+    q[0][4] = 0.5
+    g[1][5] = 0.0
+    g[1][5][9, 7] = 3.0
+    qb, gb = synth.bfloat16_bits(np.stack(q)), synth.bfloat16_bits(np.stack(g))
+    ref = oracle.similarity_matrix(list(synth.from_bfloat16_bits(qb)), list(synth.from_bfloat16_bits(gb)), precise=True)
+    sc = make_scorer("mfma")
+    got = sc.dev.to_host(sc.scores_device(sc.dev.to_device(qb), sc.dev.to_device(gb)))
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, atol=tol, rtol=0)
+
+
 def check_mfma_large_gallery(make_scorer, monkeypatch, channels, nq, ng, oracle_pairs=12):
     qb, gb, qf, gf = _bf16_sets(47, channels, nq, ng)
     mf, ff = make_scorer("mfma"), make_scorer("fft")

@@ -185,6 +185,7 @@ def test_emu_matrix_core_method_fp16():
 def test_emu_matrix_core_method_conditioning(monkeypatch, exact):
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", exact)
     pc.check_mfma_conditioning(emu_scorer)
+    pc.check_mfma_degenerate_channels(emu_scorer)
 
 
 def test_emu_matrix_core_method_split_form(monkeypatch):

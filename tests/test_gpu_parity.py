@@ -98,6 +98,7 @@ def test_matrix_core_method_fp16(lib):
 def test_matrix_core_method_conditioning(lib, monkeypatch, exact):
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", exact)
     pc.check_mfma_conditioning(_make_scorer(lib), channels=64)
+    pc.check_mfma_degenerate_channels(_make_scorer(lib))
 
 
 def test_matrix_core_method_split_form(lib, monkeypatch):
