@@ -440,11 +440,13 @@ def main(argv=None):
         launches = len(pair_events)
         if plan0.method == 4:
             # matrix-core direct form (ncc_mfma.hip): priced against the dense bf16 MFMA peak on the ALGORITHMIC flops of the
-            # sliding-window form, 2 * taps * positions per pair and channel; the kernel issues 1.33x that (template rows padded
-            # 12 -> 16 taps; 2.67x in the hi + lo form), which the fraction below therefore counts as loss; the time is that of
+            # sliding-window form as SURVEY §8d counts them - multiply-adds on in-map pixels only, 56 % of the dense taps x
+            # positions product at this size; the kernel runs the dense product and issues 1.33x it (template rows padded 12 -> 16
+            # taps; 2.67x in the hi + lo form): all of that counts as loss in `frac`; the time is that of
             # the score call: pair kernels and, in the exact form, the f32 correction-matrix kernels between them
             taps = ih * iw
-            flops_pair = 2.0 * taps * taps * c0
+            flops_pair = direct_pair_flops(ih, iw, ih, iw) * c0  # multiply-adds on in-map pixels only
+            dense = 2.0 * taps * taps * c0                       # the [queries x taps] x [taps x positions] product, zero taps included
             achieved = flops_pair * pair_pairs / (pair_ms * 1e-3) / 1e12
             exact = plans[0].gallery_item_bytes > c0 * 4032 + 4096  # the exact form's prepared items carry a V matrix
             issued = 2.0 * (ih * 16) * taps * (1 if exact else 2) * c0
@@ -454,6 +456,8 @@ def main(argv=None):
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pair_mfma_kernel" + (" + corr_mfma_kernel (exact form)" if exact else " (hi + lo form)"),
                         "launches": launches, "avg_launch_ms": round(pair_ms / launches, 3),
                         "algorithmic_gflop_per_pair": round(flops_pair / 1e9, 4),
+                        "dense_product_gflop_per_pair": round(dense / 1e9, 4),
+                        "dense_product_frac_of_peak": round(dense * pair_pairs / (pair_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                         "issued_mfma_gflop_per_pair": round(issued / 1e9, 4),
                         "issued_frac_of_peak": round(issued * pair_pairs / (pair_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                         "kernel_time_share": round(pair_ms * 1e-3 / dt, 3),

@@ -29,3 +29,12 @@ def test_clock_sampler_is_inert_without_a_matching_card():
     s = bench.ClockSampler("ffff:ff:1f.0")
     s.start()
     assert s.stop() is None
+
+
+def test_matrix_core_form_flops():
+    # ResNet50 layer3 shape, cropped 28 x 12, 1024 channels: 0.130 GFLOP per pair on in-map pixels (twice SURVEY's 512-channel
+    # conv5_3 figure), 0.231 for the dense taps x positions product, 0.308 as issued with template rows padded to 16 taps
+    assert abs(bench.direct_pair_flops(28, 12, 28, 12) * 1024 / 1e9 - 0.130) < 0.001
+    assert abs(2.0 * 336 * 336 * 1024 / 1e9 - 0.2312) < 1e-4
+    assert abs(2.0 * (28 * 16) * 336 * 1024 / 1e9 - 0.3083) < 1e-4
+    assert bench.PEAK_BF16_TFLOPS == 2500.0
