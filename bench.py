@@ -79,6 +79,21 @@ def fft_pair_flops(plan_fft, ih, iw, r_rows):
     return prod + cols + rows + weight
 
 
+def mfma_tile_steps(th, tw):
+    """(issued, all) tile steps of the matrix-core kernel per channel and 16 queries: a step = 16 positions x two template rows;
+    the kernel skips the steps whose fragment of the padded search map is all zeros (ncc_mfma.hip, MCfg::frag_zero)."""
+    tp = 3 if tw == 12 else 2
+    dy, ntile, ks_n, cy = 16 * tp // tw, th * tw // 16, th // 2, th // 2
+    issued = 0
+    for t in range(ntile):
+        tg, ph = divmod(t, tp)
+        ymin, ymax = (16 * ph) // tw, (16 * ph + 15) // tw
+        for ks in range(ks_n):
+            s_ = dy * tg + 2 * ks
+            issued += not (s_ + ymax + 1 < cy or s_ + ymin >= cy + th)
+    return issued, ntile * ks_n
+
+
 def direct_pair_flops(th, tw, ih, iw):
     """Exact-overlap multiply-adds of the direct form (15.94 GFLOP/pair at conv3_3)."""
     def ov(n_t, n_i):
@@ -449,7 +464,8 @@ def main(argv=None):
             dense = 2.0 * taps * taps * c0                       # the [queries x taps] x [taps x positions] product, zero taps included
             achieved = flops_pair * pair_pairs / (pair_ms * 1e-3) / 1e12
             exact = plans[0].gallery_item_bytes > c0 * 4032 + 4096  # the exact form's prepared items carry a V matrix
-            issued = 2.0 * (ih * 16) * taps * (1 if exact else 2) * c0
+            steps, all_steps = mfma_tile_steps(ih, iw)
+            issued = 2.0 * (ih * 16) * taps * (1 if exact else 2) * c0 * steps / all_steps  # all-zero fragments are skipped
             bytes_pair = c0 * h0 * w0 * 2
             hbm = bytes_pair * pair_pairs / (pair_ms * 1e-3) / 1e9
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -81,6 +81,19 @@ struct MCfg {
   static constexpr int kGChanBytes = 3 * 4 * NPOS;         // per channel: b, b*S1 (float), hi|lo (one word per pixel)
   // exact form: U[position][channel] (query) and V[position][channel] (gallery) follow, channels padded to 16 (zeros)
   static constexpr int kXQ = 64;                           // queries per block = row length of the correction matrix
+  // A fragment (phase ph, row offset s) reads rows s + y + {0, 1} of the padded map, y = the rows of the phase's sixteen
+  // positions; the map proper occupies rows [CY, CY + TH): a fragment entirely above or below it is all zeros - neither read
+  // nor multiplied (10 of the 26 row offsets of a phase; the tile steps on them are 18 % of all)
+  static constexpr bool frag_zero(int ph, int s) {
+    const int ymin = (16 * ph) / TW, ymax = (16 * ph + 15) / TW;
+    return s + ymax + 1 < CY || s + ymin >= CY + TH;
+  }
+  // the first k-step of tile (tg, ph) whose fragment is not all zeros: its MFMA starts the accumulator
+  static constexpr int first_ks(int tg, int ph) {
+    for (int ks = 0; ks < KS; ++ks)
+      if (!frag_zero(ph, DY * tg + 2 * ks)) return ks;
+    return KS;
+  }
 };
 __host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 
@@ -510,9 +523,11 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
       auto issue = [&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
         constexpr int sg = 2 * (j / M::TP), ph = j % M::TP, slot = j % kRing;
-        fch[slot] = load_frag(buf_cur, ph, sg, 0);
-        if constexpr (!EXACT) fcl[slot] = load_frag(buf_cur, ph, sg, 1);
-        if constexpr (sg + M::PERIOD <= M::SMAX) {
+        if constexpr (!M::frag_zero(ph, sg)) {
+          fch[slot] = load_frag(buf_cur, ph, sg, 0);
+          if constexpr (!EXACT) fcl[slot] = load_frag(buf_cur, ph, sg, 1);
+        }
+        if constexpr (sg + M::PERIOD <= M::SMAX && !M::frag_zero(ph, sg + M::PERIOD)) {
           fph[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 0);
           if constexpr (!EXACT) fpl[slot] = load_frag(buf_prev, ph, sg + M::PERIOD, 1);
         }
@@ -551,12 +566,15 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
           constexpr int t = tg * M::TP + ph;
           if constexpr (d >= 0) {
             constexpr int ks = d / 2;
-            if constexpr (ks == 0)
-              acc[t] = mfma(A[PAR][ks], fch[slot], f32x4{0.f, 0.f, 0.f, 0.f});
-            else
-              acc[t] = mfma(A[PAR][ks], fch[slot], acc[t]);
-            if constexpr (!EXACT) acc[t] = mfma(A[PAR][ks], fcl[slot], acc[t]);
-          } else {
+            static_assert(M::first_ks(tg, ph) * 2 + M::DY * tg < M::PERIOD, "a tile starts in its own channel's period");
+            if constexpr (!M::frag_zero(ph, sg)) {
+              if constexpr (ks == M::first_ks(tg, ph))
+                acc[t] = mfma(A[PAR][ks], fch[slot], f32x4{0.f, 0.f, 0.f, 0.f});
+              else
+                acc[t] = mfma(A[PAR][ks], fch[slot], acc[t]);
+              if constexpr (!EXACT) acc[t] = mfma(A[PAR][ks], fcl[slot], acc[t]);
+            }
+          } else if constexpr (!M::frag_zero(ph, sg + M::PERIOD)) {
             constexpr int ks = (d + M::PERIOD) / 2;
             acc[t] = mfma(A[PAR ^ 1][ks], fph[slot], acc[t]);
             if constexpr (!EXACT) acc[t] = mfma(A[PAR ^ 1][ks], fpl[slot], acc[t]);

@@ -38,3 +38,4 @@ def test_matrix_core_form_flops():
     assert abs(2.0 * 336 * 336 * 1024 / 1e9 - 0.2312) < 1e-4
     assert abs(2.0 * (28 * 16) * 336 * 1024 / 1e9 - 0.3083) < 1e-4
     assert bench.PEAK_BF16_TFLOPS == 2500.0
+    assert bench.mfma_tile_steps(28, 12) == (231, 294)  # 63 of the 294 tile steps fall on all-zero fragments
