@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 SEED = 1234
+CORES_VISIBLE = None  # cores in the affinity mask, before the cgroup quota / the stated 16-core share cuts them down
 SIGNAL, NOISE, MAX_SHIFT = 1, 126, 3  # the hardest queries the exact integer generator makes (signal + noise < 128):
 # true-match score ~0.006 against ~0.004 for the runner-up at conv3_3 size (tools/ubench/noise_sweep.py)
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
@@ -166,6 +167,8 @@ def usable_cores():
     (a GPU box hands a one-GPU job a share of the host: `nproc` and the affinity mask still show every core)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     how = "affinity"
+    global CORES_VISIBLE
+    CORES_VISIBLE = n
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
@@ -287,37 +290,41 @@ def main(argv=None):
     ap.add_argument("--no-parity-sample", action="store_true", help="(kept for old command lines: the parity check rides on the CPU leg)")
     ap.add_argument("--noise", type=int, default=None, help="noise amplitude of the synthetic queries (default: the workload's)")
     ap.add_argument("--no-extractor", action="store_true")
+    ap.add_argument("--max-prepared-gib", type=float, default=0.0, help="HBM budget of one prepared gallery chunk (default: automatic)")
+    ap.add_argument("--no-secondary", action="store_true", help="do not append the config-3 measurement to the default run")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--cpu-sample-queries", type=int, default=0)
     ap.add_argument("--cpu-sample-gallery", type=int, default=0)
     ap.add_argument("--emu", action="store_true", help="tests: CPU emulation of the kernels, tiny workload, gloo")
     args = ap.parse_args(argv)
-    global NOISE
-    NOISE = args.noise if args.noise is not None else WORKLOADS[args.config].get("noise", NOISE)
 
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(argv, args.gpus)
 
-    wl = WORKLOADS[args.config]
-    layer_shapes = [(EMU_LAYERS if args.emu else LAYERS)[name] for name in wl["layers"]]
-    storage = wl["storage"]
-    nq = args.queries or (4 if args.emu else wl["q"])
-    ng_local = args.gallery_per_gpu or (6 if args.emu else wl["g"])
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank_env = int(os.environ.get("RANK", "0"))
-    ng_total = ng_local * world_env
+    # The default one-GPU run of the headline workload also measures BASELINE config 3 (the bf16 small-map workload of the
+    # matrix-core scorer) and appends it as `secondary`: the same step, its own roofline / cpu_baseline / parity_sample.
+    configs = [args.config]
+    if (args.config == 2 and world_env == 1 and not args.emu and not args.no_secondary and not args.queries
+            and not args.gallery_per_gpu and args.method == "auto"):
+        configs.append(3)
 
-    # ---- CPU baseline leg first: before torch touches the GPU (fork-safe), rank 0 of a one-GPU job only ---------
-    cpu = None
+    # ---- CPU baseline legs first: before torch touches the GPU (fork-safe), rank 0 of a one-GPU job only ---------
     cores, cores_how = usable_cores()
+    cpu_legs = {}
     if world_env == 1 and rank_env == 0 and not args.no_cpu_baseline and not args.emu:
-        cpu = cpu_leg(layer_shapes[0], storage, nq, ng_total, args.cpu_seconds, cores, args.cpu_sample_queries,
-                      args.cpu_sample_gallery)
+        for cfg in configs:
+            set_noise(args, cfg)
+            wl, layer_shapes, nq, ng_local = workload_sizes(args, cfg, cfg == args.config)
+            seconds = args.cpu_seconds if cfg == args.config else min(args.cpu_seconds, 20.0)
+            cpu_legs[cfg] = cpu_leg(layer_shapes[0], wl["storage"], nq, ng_local * world_env, seconds, cores,
+                                    args.cpu_sample_queries if cfg == args.config else 0,
+                                    args.cpu_sample_gallery if cfg == args.config else 0)
 
     import torch
 
     from shoeprint_image_retrieval_amd import distributed as sdist
-    from shoeprint_image_retrieval_amd import parse_results, synth
     from shoeprint_image_retrieval_amd.similarity import NccScorer
 
     rank, world, local = sdist.init_from_env("gloo" if args.emu else None)
@@ -330,7 +337,55 @@ def main(argv=None):
         scorer = emu_scorer(args.method)
     else:
         torch.cuda.set_device(local)
-        scorer = NccScorer(method=args.method)
+        scorer = NccScorer(method=args.method,
+                           max_prepared_bytes=int(args.max_prepared_gib * (1 << 30)) if args.max_prepared_gib > 0 else None)
+    ctx = dict(rank=rank, world=world, local=local, scorer=scorer, cores=cores, cores_how=cores_how)
+    outs = []
+    for cfg in configs:
+        set_noise(args, cfg)
+        outs.append(run_config(args, cfg, ctx, cpu_legs.get(cfg), cfg == args.config))
+        if not args.emu:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    out = outs[0]
+    if len(outs) > 1:
+        out["secondary"] = outs[1:]
+    if rank == 0:
+        print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:  # leave the group together (rank 0 ran the extra legs above) and tear the backend down cleanly
+        import torch.distributed as dist
+
+        sdist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def set_noise(args, config_id):
+    global NOISE
+    NOISE = args.noise if args.noise is not None else WORKLOADS[config_id].get("noise", 126)
+
+
+def workload_sizes(args, config_id, primary):
+    """(workload, layer shapes, queries, gallery items per GPU); --queries / --gallery-per-gpu resize the primary workload only."""
+    wl = WORKLOADS[config_id]
+    layer_shapes = [(EMU_LAYERS if args.emu else LAYERS)[name] for name in wl["layers"]]
+    nq = (args.queries if primary else 0) or (4 if args.emu else wl["q"])
+    ng_local = (args.gallery_per_gpu if primary else 0) or (6 if args.emu else wl["g"])
+    return wl, layer_shapes, nq, ng_local
+
+
+def run_config(args, config_id, ctx, cpu, primary):
+    """One workload: inputs into HBM, warm-up, the timed steps, and its JSON record (rank 0's is the one printed)."""
+    import torch
+
+    from shoeprint_image_retrieval_amd import distributed as sdist
+    from shoeprint_image_retrieval_amd import parse_results, synth
+
+    rank, world, local, scorer, cores, cores_how = (ctx[k] for k in ("rank", "world", "local", "scorer", "cores", "cores_how"))
+    wl, layer_shapes, nq, ng_local = workload_sizes(args, config_id, primary)
+    storage = wl["storage"]
+    ng_total = ng_local * world
     dev, lib = scorer.dev, scorer.lib
     g0 = rank * ng_local
 
@@ -377,7 +432,7 @@ def main(argv=None):
     pgs = [dev.empty_bytes(p.gallery_item_bytes * ch) for p, ch in zip(plans, chunks)]
     layer_scores = [dev.zeros((nq, ng_local), np.float32) for _ in layers]
     scores = layer_scores[0] if len(layers) == 1 else dev.zeros((nq, ng_local), np.float32)
-    pair_events = []
+    pair_events, gather_events, gather_ms = [], [], []
     # config 5: one HIP stream per feature layer (prepare + score chains overlap), joined by events before the fusion
     streams = [torch.cuda.Stream() for _ in layers] if (len(layers) > 1 and not args.emu) else None
 
@@ -412,7 +467,19 @@ def main(argv=None):
             for k, ls in enumerate(layer_scores):
                 lib.check(lib.spr_scores_fuse(dev.ptr(scores), dev.ptr(ls), nq * ng_local, 0.0 if k == 0 else 1.0, w,
                                               dev.stream()))
-        full = as_dev(sdist.gather_score_blocks(as_torch(scores), ng_total))
+        if world > 1 and record:
+            if args.emu:
+                tg = time.perf_counter()
+                full = as_dev(sdist.gather_score_blocks(as_torch(scores), ng_total))
+                gather_ms.append((time.perf_counter() - tg) * 1e3)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                full = sdist.gather_score_blocks(scores, ng_total)
+                e1.record()
+                gather_events.append((e0, e1))
+        else:
+            full = as_dev(sdist.gather_score_blocks(as_torch(scores), ng_total))
         return scorer.ranks_device(full, match_dev), full
 
     def sync():
@@ -443,6 +510,23 @@ def main(argv=None):
     pairs_per_step = nq * ng_total
     value = pairs_per_step * args.steps / dt
     ranks = dev.to_host(ranks_dev)
+
+    # ---- N > 1: what the collective saw, and proof that every rank ended up with the same [Q, G] matrix ----------------------
+    collective = None
+    if world > 1:
+        import torch.distributed as dist
+
+        gather_ms += [a.elapsed_time(b) for a, b in gather_events]
+        digest = sdist.matrix_digest(as_torch(full))
+        digests = sdist.gather_digests(digest, device=None if args.emu else layers[0][1].device)
+        if len(set(digests)) != 1:
+            raise SystemExit(f"rank {rank}: the gathered score matrices differ between ranks: {digests}")
+        collective = {"backend": dist.get_backend(), "world_seen": dist.get_world_size(), "ranks_reporting": len(digests),
+                      "allgather_ms": round(sum(gather_ms) / max(1, len(gather_ms)), 4), "allgathers_timed": len(gather_ms),
+                      "payload_bytes": nq * ng_local * 4, "gathered_bytes": nq * ng_total * 4,
+                      "matrix_digest": f"{digests[0] & 0xFFFFFFFFFFFFFFFF:016x}", "digest_agrees_on_all_ranks": True,
+                      "timer": "perf_counter around the gloo call (emulation)" if args.emu else
+                               "HIP events on the launch stream around all_gather_into_tensor + the block re-layout"}
 
     # ---- roofline of the dominant kernel (the first layer's pair kernel), from the events recorded above ----------
     c0, h0, w0 = layer_shapes[0]
@@ -484,7 +568,7 @@ def main(argv=None):
                         "note": "v_mfma_f32_16x16x32_bf16, exact bf16 products, f32 accumulation; peak = dense bf16 2.5 PFLOP/s"}
             if observed:
                 roofline["observed"] = dict(observed, nominal_sclk_mhz=2400)
-        elif args.config == 3:
+        elif config_id == 3:
             # small maps: the kernel streams prepared spectra from L2 / HBM; SURVEY §8d prices it against HBM with the
             # compulsory bytes of an unbatched pair = one gallery feature tensor (bf16: 1.05 MB)
             bytes_pair = c0 * h0 * w0 * 2
@@ -521,14 +605,24 @@ def main(argv=None):
             # HBM-side traffic per launch: not measurable from inside the run (PMC passes need rocprofv3); the committed
             # figure of the counter passes of THIS command is used only while it is keyed to the very library build that is
             # running (sha256 of the .so), otherwise null
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r02_rocprof_summary.json")))
-                key = prof.get("pair kernel traffic per launch", {})
-                if (args.config, nq, ng_local, world) == (2, wl["q"], wl["g"], 1) and key.get("lib_sha16") == lib_sha16(lib.path):
-                    roofline["traffic"] = key["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes per launch (memory-side L2 requests incl. Infinity-Cache hits)"
-            except (OSError, KeyError, ValueError):
-                pass
+            import glob
+
+            sha = lib_sha16(lib.path)
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_summary.json")), reverse=True):
+                try:
+                    key = json.load(open(path)).get("pair kernel traffic per launch", {})
+                    if (config_id, nq, ng_local, world) == (2, wl["q"], wl["g"], 1) and key.get("lib_sha16") == sha:
+                        roofline["traffic"] = key["hbm_bytes_per_launch"]
+                        roofline["traffic_unit"] = "bytes per launch (memory-side L2 requests incl. Infinity-Cache hits)"
+                        roofline["traffic_source"] = (f"NOT measured in this run: the committed rocprofv3 --pmc passes of this "
+                                                      f"command ({os.path.relpath(path, ROOT)}), used because the running "
+                                                      f"library's sha256 {sha} is the build those passes profiled")
+                        break
+                except (OSError, KeyError, ValueError):
+                    continue
+            if roofline["traffic"] is None:
+                roofline["traffic_source"] = ("none: no committed counter pass is keyed to this library build "
+                                              f"(sha256 {sha}); PMC counters cannot be read from inside the run")
 
     shapes = " + ".join(f"[{c},{h},{w}]" for c, h, w in layer_shapes)
     out = {
@@ -536,7 +630,7 @@ def main(argv=None):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if plan0.method == 4 else "f32", "data": "synthetic",
-        "config": {"workload": f"config {args.config}: {wl['name']}: Q={nq} x G={ng_total} ({ng_local}/GPU), features {shapes} "
+        "config": {"workload": f"config {config_id}: {wl['name']}: Q={nq} x G={ng_total} ({ng_local}/GPU), features {shapes} "
                                f"stored as {storage}, rotations/scales none, queries signal {SIGNAL} / noise {NOISE}",
                    "method": {1: "fft", 2: "direct", 4: "mfma"}[plan0.method], "fft_grid": list(plan0.fft_size),
                    "gallery_chunk": chunks[0], "gallery_chunks_per_step": math.ceil(ng_local / chunks[0]),
@@ -547,10 +641,12 @@ def main(argv=None):
     }
     if roofline:
         out["roofline"] = roofline
+    if collective:
+        out["collective"] = collective
     if args.emu:
         out["data"] = "synthetic (CPU emulation of the kernels: test mode, not a measurement)"
 
-    if rank == 0 and not args.no_extractor and not args.emu and args.config == 3:
+    if rank == 0 and not args.no_extractor and not args.emu and config_id == 3:
         # the build-defined ResNet50-layer3 extractor, reported separately (17.13 GFLOP per 512x256 image)
         from shoeprint_image_retrieval_amd import network
         model = network.Model({"model": {"type": "ResNet50", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 7)
@@ -570,7 +666,7 @@ def main(argv=None):
                             "frac": round(17.13 * 32 / ems / PEAK_FP32_TFLOPS, 4), "bound": "mfma", "dtype": "f32",
                             "weights": "seeded synthetic"}
         del model, imgs
-    if rank == 0 and not args.no_extractor and not args.emu and args.config == 2:
+    if rank == 0 and not args.no_extractor and not args.emu and config_id == 2:
         # extractor reported separately: VGG16 features[:16] on 512x256 prints, images/s
         from shoeprint_image_retrieval_amd import network
         model = network.Model({"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 16)
@@ -594,7 +690,7 @@ def main(argv=None):
     if cpu is not None:
         v = cpu["pairs_per_s"]
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-                               "cores_from": cores_how, "cpu_model": cpu_model(),
+                               "cores_from": cores_how, "cores_visible": CORES_VISIBLE, "cpu_model": cpu_model(),
                                "sample": f"queries 0..{cpu['sq'] - 1} x {len(cpu['g_ids'])} gallery items (their matches included) of the "
                                          f"same workload, first layer, oracle compare_maps with a {cores}-process pool, "
                                          f"{cpu['seconds']:.1f} s",
@@ -623,15 +719,7 @@ def main(argv=None):
                                     "rank_vector_places_that_differ": swaps,
                                     "largest_oracle_score_gap_at_such_a_place": float(f"{gap:.3e}"),
                                     "oracle_ranks": [int(r) for r in cpu["ranks"]]}
-    if rank == 0:
-        print(json.dumps(out))
-    sys.stdout.flush()
-    if world > 1:  # leave the group together (rank 0 ran the extra legs above) and tear the backend down cleanly
-        import torch.distributed as dist
-
-        sdist.barrier()
-        dist.destroy_process_group()
-    return 0
+    return out
 
 
 if __name__ == "__main__":

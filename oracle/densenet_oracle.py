@@ -16,6 +16,49 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 
+# ---- the architecture, restated here independently of the library under test: torchvision densenet201 = growth rate 32,
+# block_config (6, 12, 48, 32), 64 initial features, bottleneck width 4 x 32 ------------------------------------------------
+GROWTH, BLOCKS, INIT, BOTTLENECK = 32, (6, 12, 48, 32), 64, 128
+FEATURE_NAMES = ("conv0", "norm0", "relu0", "pool0", "denseblock1", "transition1", "denseblock2", "transition2", "denseblock3",
+                 "transition3", "denseblock4", "norm5")
+
+
+def arch_ops(block: int) -> list[dict]:
+    """features[:block] (network.py:185-186) as the layer list the tests compare Model.densenet_ops with: kind 0 stem (flags:
+    1 norm0, 2 relu0, 4 pool0 inside the cut), 1 dense 1x1 (with both BatchNorms), 2 dense 3x3, 3 transition, 4 norm5;
+    `ctot` = the width of the tensor the layer reads from / appends to once its block is complete; module names attached."""
+    ops = []
+    if block < 1:
+        return ops
+    ops.append(dict(kind=0, cin=3, cout=INIT, c_off=0, ctot=INIT, flags=(block >= 2) | 2 * (block >= 3) | 4 * (block >= 4),
+                    feature=0, names=("features.conv0", "features.norm0")))
+    width = INIT
+    for b, layers in enumerate(BLOCKS):
+        f = 4 + 2 * b
+        if block <= f:
+            break
+        total = width + layers * GROWTH
+        for l in range(layers):
+            pre = f"features.denseblock{b + 1}.denselayer{l + 1}"
+            ops.append(dict(kind=1, cin=width + l * GROWTH, cout=BOTTLENECK, c_off=0, ctot=total, flags=0, feature=f,
+                            names=(f"{pre}.norm1", f"{pre}.conv1", f"{pre}.norm2")))
+            ops.append(dict(kind=2, cin=BOTTLENECK, cout=GROWTH, c_off=width + l * GROWTH, ctot=total, flags=0, feature=f,
+                            names=(f"{pre}.conv2",)))
+        width = total
+        if b == len(BLOCKS) - 1:
+            if block > f + 1:
+                ops.append(dict(kind=4, cin=width, cout=width, c_off=0, ctot=width, flags=0, feature=f + 1, names=("features.norm5",)))
+            break
+        if block <= f + 1:
+            break
+        ops.append(dict(kind=3, cin=width, cout=width // 2, c_off=0, ctot=width, flags=0, feature=f + 1,
+                        names=(f"features.transition{b + 1}.norm", f"features.transition{b + 1}.conv")))
+        width //= 2
+    return ops
+
+
+ARCH_KEYS = ("kind", "cin", "cout", "flags", "feature")
+
 
 def _bn(x, p):
     g, b, m, v = (torch.from_numpy(np.asarray(t, dtype=np.float32)) for t in p)

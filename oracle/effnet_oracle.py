@@ -18,6 +18,82 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3
 
+# ---- the architecture, restated here independently of the library under test -------------------------------------------------
+# torchvision.models.efficientnet: (fused, expand ratio, kernel, stride, input width, output width, layers) per stage.
+_V2 = {
+    "EfficientNetV2_S": [(1, 1, 3, 1, 24, 24, 2), (1, 4, 3, 2, 24, 48, 4), (1, 4, 3, 2, 48, 64, 4), (0, 4, 3, 2, 64, 128, 6),
+                         (0, 6, 3, 1, 128, 160, 9), (0, 6, 3, 2, 160, 256, 15)],
+    "EfficientNetV2_M": [(1, 1, 3, 1, 24, 24, 3), (1, 4, 3, 2, 24, 48, 5), (1, 4, 3, 2, 48, 80, 5), (0, 4, 3, 2, 80, 160, 7),
+                         (0, 6, 3, 1, 160, 176, 14), (0, 6, 3, 2, 176, 304, 18), (0, 6, 3, 1, 304, 512, 5)],
+    "EfficientNetV2_L": [(1, 1, 3, 1, 32, 32, 4), (1, 4, 3, 2, 32, 64, 7), (1, 4, 3, 2, 64, 96, 7), (0, 4, 3, 2, 96, 192, 10),
+                         (0, 6, 3, 1, 192, 224, 19), (0, 6, 3, 2, 224, 384, 25), (0, 6, 3, 1, 384, 640, 7)],
+}
+_B0 = [(0, 1, 3, 1, 32, 16, 1), (0, 6, 3, 2, 16, 24, 2), (0, 6, 5, 2, 24, 40, 2), (0, 6, 3, 2, 40, 80, 3),
+       (0, 6, 5, 1, 80, 112, 3), (0, 6, 5, 2, 112, 192, 4), (0, 6, 3, 1, 192, 320, 1)]
+_B_MULT = {"EfficientNet_B1": (1.0, 1.1), "EfficientNet_B2": (1.1, 1.2), "EfficientNet_B3": (1.2, 1.4),
+           "EfficientNet_B4": (1.4, 1.8), "EfficientNet_B5": (1.6, 2.2), "EfficientNet_B6": (1.8, 2.6),
+           "EfficientNet_B7": (2.0, 3.1)}
+# BatchNorm eps as torchvision builds the models: 1e-3 for efficientnet_v2_* and b5 / b6 / b7, the default 1e-5 otherwise
+EPS = {**{k: 1e-3 for k in _V2}, **{k: (1e-3 if k[-1] in "567" else 1e-5) for k in _B_MULT}}
+
+
+def make_divisible(v: float, divisor: int = 8) -> int:
+    """torchvision.models._utils._make_divisible with min_value = divisor."""
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+def stages(model_str: str):
+    if model_str in _V2:
+        return list(_V2[model_str])
+    wm, dm = _B_MULT[model_str]
+    import math
+    return [(f, e, k, s, make_divisible(ci * wm), make_divisible(co * wm), int(math.ceil(n * dm))) for f, e, k, s, ci, co, n in _B0]
+
+
+def arch_ops(model_str: str, block: int) -> list[dict]:
+    """features[:block] (network.py:185-186) flattened into convolutions (kind 0), depthwise convolutions (1) and
+    squeeze-excitations (2), with the module name of every layer in a torchvision state dict.  act: 2 = SiLU, 0 = none."""
+    st = stages(model_str)
+    ops = [dict(kind=0, cin=3, cout=st[0][4], ks=3, stride=2, act=2, res=0, sq=0, feature=0, block_end=1,
+                names=("features.0.0", "features.0.1"))]
+    for si, (fused, expand, ks, stride0, cin0, cout, layers) in enumerate(st[: max(0, block - 1)]):
+        for l in range(layers):
+            cin, stride = (cin0, stride0) if l == 0 else (cout, 1)
+            exp = make_divisible(cin * expand)
+            res = int(stride == 1 and cin == cout)
+            pre = f"features.{si + 1}.{l}.block"
+            k = 0
+
+            def conv(ci, co, kk, s, act, r, end):
+                nonlocal k
+                ops.append(dict(kind=0, cin=ci, cout=co, ks=kk, stride=s, act=act, res=r, sq=0, feature=si + 1, block_end=end,
+                                names=(f"{pre}.{k}.0", f"{pre}.{k}.1")))
+                k += 1
+
+            if fused:
+                if exp != cin:
+                    conv(cin, exp, ks, stride, 2, 0, 0)
+                    conv(exp, cout, 1, 1, 0, res, 1)
+                else:
+                    conv(cin, cout, ks, stride, 2, res, 1)
+                continue
+            if exp != cin:
+                conv(cin, exp, 1, 1, 2, 0, 0)
+            ops.append(dict(kind=1, cin=exp, cout=exp, ks=ks, stride=stride, act=2, res=0, sq=0, feature=si + 1, block_end=0,
+                            names=(f"{pre}.{k}.0", f"{pre}.{k}.1")))
+            k += 1
+            ops.append(dict(kind=2, cin=exp, cout=exp, ks=0, stride=0, act=0, res=0, sq=max(1, cin // 4), feature=si + 1,
+                            block_end=0, names=(f"{pre}.{k}.fc1", f"{pre}.{k}.fc2")))
+            k += 1
+            conv(exp, cout, 1, 1, 0, res, 1)
+    return ops
+
+
+ARCH_KEYS = ("kind", "cin", "cout", "ks", "stride", "act", "res", "sq", "feature", "block_end")
+
 
 def get_feature_maps(img: np.ndarray, ops, parameters, mean, std, bn_eps: float = BN_EPS) -> np.ndarray:
     """uint8 [H,W] or RGB [H,W,3] (already CLAHE'd) -> float32 [C,h,w].  ``ops``: the layer list of Model.effnet_ops (kind,

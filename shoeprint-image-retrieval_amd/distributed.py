@@ -70,6 +70,28 @@ def gather_score_blocks(local_scores, n_gallery: int, group=None):
     return torch.cat([recv[r, :, : e - s] for r, (s, e) in enumerate(widths)], dim=1).contiguous()
 
 
+def matrix_digest(matrix) -> int:
+    """64-bit position-weighted checksum of a float32 matrix's bit patterns (computed where the matrix lives)."""
+    import torch
+
+    bits = matrix.contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    weight = torch.arange(bits.numel(), dtype=torch.int64, device=bits.device) % 1000003 + 1
+    return int((bits * weight).sum().item())
+
+
+def gather_digests(digest: int, device=None, group=None) -> list[int]:
+    """Every rank's digest on every rank (all_gather of one int64 each)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return [digest]
+    mine = torch.tensor([digest], dtype=torch.int64, device=device if device is not None else "cpu")
+    out = torch.empty((dist.get_world_size(group),), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return [int(v) for v in out.tolist()]
+
+
 def barrier(group=None):
     import torch.distributed as dist
 

@@ -156,9 +156,11 @@ class NccScorer:
                                               self.dev.ptr(scores), ld, col0, 1 if accumulate_max else 0,
                                               self.dev.stream()))
 
-    def gallery_chunk_items(self, plan: _Plan, n_gallery: int) -> int:
+    def gallery_chunk_items(self, plan: _Plan, n_gallery: int, share: int = 1) -> int:
+        """Gallery items per prepared chunk; ``share`` = how many prepared forms of the chunk are alive at once (one per
+        distinct query-variant shape: the 1/sigma map depends on the template size) and split the budget."""
         per_item = plan.gallery_item_bytes
-        return int(max(1, min(n_gallery, self._budget() // max(1, per_item), 65535)))
+        return int(max(1, min(n_gallery, self._budget() // max(1, share) // max(1, per_item), 65535)))
 
     def scores_device(self, q_dev, g_dev, scores=None, accumulate_max: bool = False, plan: _Plan | None = None):
         """[Q,G] float32 score matrix (device) of a uniform query batch [Q,C,h,w] against a uniform
@@ -250,7 +252,9 @@ class NccScorer:
                     raise ValueError(f"channel mismatch: query {qshape}, gallery {gshape}")
                 for vs in by_shape:
                     plans[vs] = self.plan(qshape[0], vs, gshape[1:], dtype=self.storage)
-            chunk = min(self.gallery_chunk_items(p, len(g_idx)) for p in plans.values())
+            # every plan's prepared form of a chunk stays alive while the query groups are walked: they share the budget
+            chunk = min(self.gallery_chunk_items(p, len(g_idx), share=len(plans)) for p in plans.values())
+            self.last_chunk_items = chunk  # (read by the tests)
             for start in range(0, len(g_idx), chunk):
                 idx = g_idx[start:start + chunk]
                 g_batch = self.dev.astype_storage(self.dev.stack_to_device([g_items[i] for i in idx]), self.storage)

@@ -65,6 +65,32 @@ def check_resnet50(block, hw, device, lib, n_images=2, tol=5e-5):
     m.close()
 
 
+def check_effnet_tables(model_str, block, ops):
+    """The library's flattened layer list and the state-dict names derived from it against the oracle's OWN restatement of
+    torchvision's architecture tables (stage settings, width / depth scaling, _make_divisible, squeeze widths, residual
+    flags, module names) - the oracle graph must not be taken from the library it checks."""
+    from oracle import effnet_oracle
+
+    want = effnet_oracle.arch_ops(model_str, block)
+    assert len(ops) == len(want), (model_str, block, len(ops), len(want))
+    for i, (a, b) in enumerate(zip(ops, want)):
+        keys = [k for k in effnet_oracle.ARCH_KEYS if not (b["kind"] == 2 and k in ("ks", "stride", "act"))]
+        assert {k: a[k] for k in keys} == {k: b[k] for k in keys}, (model_str, block, i, a, b)
+    assert network.effnet_state_names(ops) == [o["names"] for o in want]
+    assert network._EFFNET_MODELS[model_str][3] == effnet_oracle.EPS[model_str]
+
+
+def check_densenet_tables(block, ops):
+    from oracle import densenet_oracle
+
+    want = densenet_oracle.arch_ops(block)
+    assert len(ops) == len(want), (block, len(ops), len(want))
+    for i, (a, b) in enumerate(zip(ops, want)):
+        keys = densenet_oracle.ARCH_KEYS + (("c_off", "ctot") if b["kind"] in (1, 2) else ())
+        assert {k: a[k] for k in keys} == {k: b[k] for k in keys}, (block, i, a, b)
+    assert [tuple(n) for n in network.densenet_state_names(ops)] == [o["names"] for o in want]
+
+
 def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=False):
     """An EfficientNetV2 truncation features[:block] (the reference's run.toml default is EfficientNetV2_M, blocks 4 .. 6)
     against the torch-CPU oracle with the same seeded parameters; parity unpinned (no torchvision offline).  Tolerance:
@@ -74,10 +100,8 @@ def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=Fa
     cfg = {"model": dict(CFG["model"], type=model_str), "comparison": CFG["comparison"]}
     m = network.Model(cfg, block, device=device, library=lib)
     ops = m.effnet_ops()
+    check_effnet_tables(model_str, block, ops)
     params = synth.effnet_parameters(1234, ops)
-    names = network.effnet_state_names(ops)
-    assert names[0] == ("features.0.0", "features.0.1") and len(names) == len(ops)
-    assert all(n[0].startswith(f"features.{op['feature']}.") for n, op in zip(names, ops))
     if rgb:
         imgs = np.stack([np.stack([synth.shoeprint_image(8 + c, i, *hw) for c in range(3)], axis=-1) for i in range(n_images)])
     else:
@@ -98,9 +122,8 @@ def check_densenet(block, hw, device, lib, n_images=2, tol=5e-5):
     cfg = {"model": dict(CFG["model"], type="DenseNet_201"), "comparison": CFG["comparison"]}
     m = network.Model(cfg, block, device=device, library=lib)
     ops = m.densenet_ops()
+    check_densenet_tables(block, ops)
     params = synth.densenet_parameters(1234, ops)
-    names = network.densenet_state_names(ops)
-    assert len(names) == len(ops) and names[0] == ("features.conv0", "features.norm0")
     imgs = np.stack([synth.shoeprint_image(8, i, *hw) for i in range(n_images)])
     got = device.to_host(m.extract_device(device.to_device(imgs)))
     assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)

@@ -453,6 +453,24 @@ def check_variant_accumulate(scorer):
     np.testing.assert_allclose(mat, ref, atol=TIGHT)
 
 
+def check_variant_chunk_budget(make_scorer):
+    """Scaled variants give one plan (and one prepared form of every gallery chunk) per distinct query shape; all of them
+    are alive while a chunk is scored, so together they must fit the HBM budget of 'one prepared chunk' - and chunking must
+    not change a score."""
+    q, g, _ = synth.dataset(11, 3, 7, 2, 20, 14, signal=1, noise=6)
+    scales = [1.1, 1.25]  # 16 x 10 cropped maps -> three distinct variant shapes
+    whole = make_scorer()
+    ref = whole.score_matrix(q, g, scales=scales)
+    plans = [p for p in whole._plans.values()]
+    assert len({p.q_hw for p in plans}) == 3
+    per_item_all = sum(p.gallery_item_bytes for p in plans)
+    budget = 3 * max(p.gallery_item_bytes for p in plans) * 2 + 17  # room for two items of every form, not for three
+    small = make_scorer(max_prepared_bytes=budget)
+    got = small.score_matrix(q, g, scales=scales)
+    assert small.last_chunk_items == 2 and small.last_chunk_items * per_item_all <= budget
+    np.testing.assert_array_equal(got, ref)
+
+
 def check_variants(scorer):
     """f1: rotated / scaled query variants are bit-identical to Pillow's (golden from the real reference),
     and the running-max matrix / ranks over variants match the reference."""

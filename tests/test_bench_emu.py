@@ -30,6 +30,14 @@ def test_plain_gpus2_invocation_starts_its_own_workers_and_matches_one_process()
     for key in ("rank1", "mAP", "mean_rank"):
         assert one[key] == two[key]
     assert two["value"] > 0 and two["unit"] == "pairs/s" and two["metric"].startswith("query x gallery NCC")
+    # the N > 1 line proves what the collective saw: backend, ranks, timed all-gather, payload, and that every rank holds
+    # the same gathered matrix (bench.py exits non-zero when the digests differ)
+    assert "collective" not in one
+    col = two["collective"]
+    assert col["backend"] == "gloo" and col["world_seen"] == 2 and col["ranks_reporting"] == 2
+    assert col["payload_bytes"] == 4 * 6 * 4 and col["gathered_bytes"] == 4 * 12 * 4
+    assert col["allgather_ms"] > 0 and col["allgathers_timed"] == 1 and col["digest_agrees_on_all_ranks"] is True
+    assert len(col["matrix_digest"]) == 16
 
 
 @pytest.mark.parametrize("config", [3, 4, 5])

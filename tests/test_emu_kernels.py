@@ -111,6 +111,10 @@ def test_emu_accumulate_and_floor(scorer):
     pc.check_variant_accumulate(scorer)
 
 
+def test_emu_variant_chunk_budget():
+    pc.check_variant_chunk_budget(lambda **kw: emu_scorer("fft", **kw))
+
+
 def test_emu_gallery_chunking_matches_single_pass():
     from shoeprint_image_retrieval_amd import synth
 
