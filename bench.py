@@ -211,11 +211,12 @@ def storage_round(a: np.ndarray, storage: str) -> np.ndarray:
     return a
 
 
-def cpu_leg(layer_shape, storage, nq_total, ng_total, target_seconds, cores, sample_q, sample_g):
+def cpu_leg(layer_shape, storage, nq_total, ng_total, target_seconds, cores, sample_q, sample_g, more_layers=()):
     """The CPU oracle's compare_maps (process pool over query chunks, scipy FFT per channel: the reference's
     formulation) on a bounded sample of the SAME workload: queries 0 .. sq-1 against a gallery subset that holds their
     true matches.  Returns pairs/s and the oracle's float32 score block + ranks for the parity check.  Runs before the
-    GPU is initialised in this process: the pool forks."""
+    GPU is initialised in this process: the pool forks.  `more_layers` (config 5): the further feature layers of the sampled
+    block are scored too, outside the timed region, and the mean over all layers is returned for the parity check."""
     from oracle import ncc_oracle as oracle  # baseline / checker leg only
     from shoeprint_image_retrieval_amd import synth
 
@@ -224,7 +225,7 @@ def cpu_leg(layer_shape, storage, nq_total, ng_total, target_seconds, cores, sam
     sq = sample_q or max(8, min(nq_total, cores))
     cfg = {"comparison": {"n_processes": cores, "rotations": None, "scales": None}}
 
-    def features(q_ids, g_ids):
+    def features(q_ids, g_ids, c=c, h=h, w=w):
         gal = [storage_round(synth.gallery_features(SEED, g, c, h, w), storage) for g in g_ids]
         qs = [storage_round(synth.query_features(SEED, q, int(matches[q]), c, h, w, max_shift=MAX_SHIFT, signal=SIGNAL,
                                                  noise=NOISE), storage) for q in q_ids]
@@ -249,8 +250,16 @@ def cpu_leg(layer_shape, storage, nq_total, ng_total, target_seconds, cores, sam
     t0 = time.perf_counter()
     ranks, matrix = oracle.compare_maps(queries, gallery, local_match, cfg, return_matrix=True)
     dt = time.perf_counter() - t0
+    matrix = np.asarray(matrix, dtype=np.float32)
+    if more_layers:  # the fused score of the multi-layer workload = mean of the per-layer float32 matrices (as on the device)
+        total = matrix.astype(np.float64)
+        for shape in more_layers:
+            qs, gal = features(range(sq), g_ids, *shape)
+            total += np.asarray(oracle.compare_maps(qs, gal, local_match, cfg, return_matrix=True)[1], dtype=np.float32)
+        matrix = (total / (1 + len(more_layers))).astype(np.float32)
+        ranks = [oracle.rank_true_match(matrix[i], local_match[i]) for i in range(sq)]
     return {"pairs_per_s": sq * len(g_ids) / dt, "seconds": dt, "sq": sq, "g_ids": g_ids, "local_match": local_match,
-            "ranks": np.asarray(ranks), "matrix": np.asarray(matrix, dtype=np.float32)}
+            "ranks": np.asarray(ranks), "matrix": matrix, "layers": 1 + len(more_layers)}
 
 
 def self_launch(argv, gpus):
@@ -320,7 +329,7 @@ def main(argv=None):
             seconds = args.cpu_seconds if cfg == args.config else min(args.cpu_seconds, 20.0)
             cpu_legs[cfg] = cpu_leg(layer_shapes[0], wl["storage"], nq, ng_local * world_env, seconds, cores,
                                     args.cpu_sample_queries if cfg == args.config else 0,
-                                    args.cpu_sample_gallery if cfg == args.config else 0)
+                                    args.cpu_sample_gallery if cfg == args.config else 0, more_layers=layer_shapes[1:])
 
     import torch
 
@@ -695,8 +704,8 @@ def run_config(args, config_id, ctx, cpu, primary):
                                          f"same workload, first layer, oracle compare_maps with a {cores}-process pool, "
                                          f"{cpu['seconds']:.1f} s",
                                "per_core": round(v / cores, 2), "gpu_over_cpu": round(value / v, 1)}
-        if len(layers) == 1:
-            # parity on the ACTUAL workload: the GPU's scores of the sampled block against the oracle's, and the full
+        if True:
+            # parity on the ACTUAL workload (multi-layer: the fused matrix against the mean of the oracle's per-layer ones): the GPU's scores of the sampled block against the oracle's, and the full
             # rank vector of every sampled query (ranked within the sampled gallery, by the oracle's rule, from GPU scores)
             full_h = dev.to_host(full)
             block = full_h[np.ix_(range(cpu["sq"]), cpu["g_ids"])]
@@ -718,7 +727,7 @@ def run_config(args, config_id, ctx, cpu, primary):
                                     "full_rank_vectors_equal": bool(order_equal),
                                     "rank_vector_places_that_differ": swaps,
                                     "largest_oracle_score_gap_at_such_a_place": float(f"{gap:.3e}"),
-                                    "oracle_ranks": [int(r) for r in cpu["ranks"]]}
+                                    "oracle_ranks": [int(r) for r in cpu["ranks"]], "layers": cpu["layers"]}
     return out
 
 

@@ -494,6 +494,13 @@ class Model:
         dev = self.dev
         shape = dev.shape(images_dev)
         n, h, w = shape[0], shape[1], shape[2]
+        if self.arch >= 0 and not self.effnet and dev.name == "hip" and self.lib is _lib.load_library():
+            from . import _torch_ops
+
+            if _torch_ops.enabled() and images_dev.is_contiguous() and len(shape) == (4 if in_channels == 3 else 3):
+                # the registered PyTorch-ROCm custom op (csrc/torch_ops.cpp): same plan, same kernels, current stream
+                return _torch_ops.load().extract(images_dev, self.packed, self.arch, self.block, [float(m) for m in self.mean],
+                                                 [float(s) for s in self.std])
         c, oh, ow = self.output_shape(h, w)
         out = dev.empty((n, c, oh, ow), np.float32)
         ws_fn = (self.lib.spr_densenet_workspace_bytes if self.densenet else self.lib.spr_effnet_workspace_bytes if self.effnet else

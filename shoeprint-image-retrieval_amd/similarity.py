@@ -171,6 +171,11 @@ class NccScorer:
         ng, c2, gh, gw = self.dev.shape(g_dev)
         if c != c2:
             raise ValueError(f"channel mismatch: queries {c}, gallery {c2}")
+        if plan is None and scores is None and not accumulate_max and self._torch_ops() is not None:
+            # north_star's named mechanism: the registered PyTorch-ROCm custom op (csrc/torch_ops.cpp), same entry points
+            if str(q_dev.dtype) != str(g_dev.dtype):
+                raise ValueError(f"storage type mismatch: queries {q_dev.dtype}, gallery {g_dev.dtype}")
+            return self._torch_ops().ncc_scores(q_dev, g_dev, self.crop, _lib.METHOD_NAMES[self.method], self._budget())
         if plan is None:
             if str(q_dev.dtype) != str(g_dev.dtype):
                 raise ValueError(f"storage type mismatch: queries {q_dev.dtype}, gallery {g_dev.dtype}")
@@ -194,8 +199,20 @@ class NccScorer:
     def _offset(self, byte_buf, nbytes: int):
         return byte_buf if nbytes == 0 else self.dev.narrow0(byte_buf, nbytes, self.dev.shape(byte_buf)[0] - nbytes)
 
+    def _torch_ops(self):
+        """torch.ops.shoeprint_mi355x when this scorer runs the in-tree library on PyTorch-ROCm tensors and the op library
+        is built (and not switched off with SPR_TORCH_OPS=0); None otherwise (emulation tests, explicit libraries)."""
+        if getattr(self, "_ops_cache", False) is False:
+            from . import _torch_ops
+
+            ok = (self.dev.name == "hip" and self.lib is _lib.load_library() and _torch_ops.enabled())
+            self._ops_cache = _torch_ops.load() if ok else None
+        return self._ops_cache
+
     def ranks_device(self, scores, match_dev):
         nq, ng = self.dev.shape(scores)
+        if nq > 0 and self._torch_ops() is not None and scores.is_contiguous() and match_dev.is_contiguous():
+            return self._torch_ops().ranks(scores, match_dev)
         ranks = self.dev.zeros((max(nq, 1),), np.int32)
         self.lib.check(self.lib.spr_rank_true_match(self.dev.ptr(scores), ng, nq, ng, self.dev.ptr(match_dev),
                                                     self.dev.ptr(ranks), self.dev.stream()))

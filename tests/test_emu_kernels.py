@@ -266,3 +266,25 @@ print("UBSAN-CLEAN")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "UBSAN-CLEAN" in out.stdout
+
+
+def test_torch_ops_are_registered_and_refuse_cpu_tensors():
+    """torch.ops.shoeprint_mi355x (csrc/torch_ops.cpp): the TORCH_LIBRARY registration north_star names.  Without a GPU:
+    the extension loads, the three operators carry the schemas SURVEY 8(b) lists, and - there being no CPU path - a CPU
+    tensor is refused loudly."""
+    import torch
+    from shoeprint_image_retrieval_amd import _torch_ops
+
+    ops = _torch_ops.load()
+    schemas = {n: str(getattr(ops, n).default._schema) for n in ("ncc_scores", "ranks", "extract")}
+    assert schemas["ncc_scores"] == ('shoeprint_mi355x::ncc_scores(Tensor q, Tensor g, int crop=2, str method="auto", '
+                                     'int max_prepared_bytes=0) -> Tensor')
+    assert schemas["ranks"] == "shoeprint_mi355x::ranks(Tensor scores, Tensor match) -> Tensor"
+    assert schemas["extract"].startswith("shoeprint_mi355x::extract(Tensor images, Tensor packed, int arch, int block, float[] mean")
+    with pytest.raises(RuntimeError, match="must live in HBM"):
+        ops.ncc_scores(torch.zeros(1, 2, 8, 8), torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match="must live in HBM"):
+        ops.ranks(torch.zeros(2, 3), torch.zeros(2, dtype=torch.int32))
+    # both shared objects resolve to the same C-ABI library: the op library links it, it does not carry a second copy
+    maps = open("/proc/self/maps").read()
+    assert "libshoeprint_torch_ops.so" in maps and "libshoeprint_mi355x.so" in maps
