@@ -655,46 +655,48 @@ def run_config(args, config_id, ctx, cpu, primary):
     if args.emu:
         out["data"] = "synthetic (CPU emulation of the kernels: test mode, not a measurement)"
 
-    if rank == 0 and not args.no_extractor and not args.emu and config_id == 3:
-        # the build-defined ResNet50-layer3 extractor, reported separately (17.13 GFLOP per 512x256 image)
+    if rank == 0 and not args.no_extractor and not args.emu and config_id in (2, 3):
+        # the extractor, reported separately: images/s on 512x256 prints with seeded synthetic weights, in the
+        # reference's float32 arithmetic (the f32 matrix cores) and on the 16-bit matrix cores (bfloat16 operands, f32 sums)
         from shoeprint_image_retrieval_amd import network
-        model = network.Model({"model": {"type": "ResNet50", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 7)
+
+        mtype, block, gflop, what = (("VGG16", 16, 48.77, "VGG16 features[:16] images/s (512x256 uint8 -> [256,128,64] f32)")
+                                     if config_id == 2 else
+                                     ("ResNet50", 7, 17.13, "ResNet50 layer3 images/s (512x256 uint8 -> [1024,32,16] f32)"))
         imgs = torch.randint(0, 256, (32, 512, 256), dtype=torch.uint8, device=layers[0][1].device)
-        model.extract_device(imgs)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
+
+        def time_model(compute):
+            cfg = {"model": {"type": mtype, "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]},
+                   "mi355x": {"extractor_dtype": compute}}
+            model = network.Model(cfg, block)
             model.extract_device(imgs)
-        e1.record()
-        torch.cuda.synchronize()
-        ems = e0.elapsed_time(e1) / 3
-        out["extractor"] = {"metric": "ResNet50 layer3 images/s (512x256 uint8 -> [1024,32,16] f32)",
-                            "value": round(32 / ems * 1e3, 1), "batch": 32, "ms_per_batch": round(ems, 2),
-                            "achieved_tflops": round(17.13 * 32 / ems, 2), "peak_tflops": PEAK_FP32_TFLOPS,
-                            "frac": round(17.13 * 32 / ems / PEAK_FP32_TFLOPS, 4), "bound": "mfma", "dtype": "f32",
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                model.extract_device(imgs)
+            e1.record()
+            torch.cuda.synchronize()
+            ems = e0.elapsed_time(e1) / 5
+            model.close()
+            return ems
+
+        ems = time_model("float32")
+        out["extractor"] = {"metric": what, "value": round(32 / ems * 1e3, 1), "batch": 32, "ms_per_batch": round(ems, 2),
+                            "achieved_tflops": round(gflop * 32 / ems, 2), "peak_tflops": PEAK_FP32_TFLOPS,
+                            "frac": round(gflop * 32 / ems / PEAK_FP32_TFLOPS, 4), "bound": "mfma", "dtype": "f32",
                             "weights": "seeded synthetic"}
-        del model, imgs
-    if rank == 0 and not args.no_extractor and not args.emu and config_id == 2:
-        # extractor reported separately: VGG16 features[:16] on 512x256 prints, images/s
-        from shoeprint_image_retrieval_amd import network
-        model = network.Model({"model": {"type": "VGG16", "clahe_clip_limit": 2.0, "clahe_tile_grid_size": [8, 8]}}, 16)
-        imgs = torch.randint(0, 256, (32, 512, 256), dtype=torch.uint8, device=layers[0][1].device)
-        model.extract_device(imgs)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            model.extract_device(imgs)
-        e1.record()
-        torch.cuda.synchronize()
-        ems = e0.elapsed_time(e1) / 3
-        out["extractor"] = {"metric": "VGG16 features[:16] images/s (512x256 uint8 -> [256,128,64] f32)",
-                            "value": round(32 / ems * 1e3, 1), "batch": 32, "ms_per_batch": round(ems, 2),
-                            "achieved_tflops": round(48.77 * 32 / ems, 2), "peak_tflops": PEAK_FP32_TFLOPS,
-                            "frac": round(48.77 * 32 / ems / PEAK_FP32_TFLOPS, 4), "bound": "mfma", "dtype": "f32",
-                            "weights": "seeded synthetic"}
-        del model, imgs
+        try:
+            ems16 = time_model("bfloat16")
+            out["extractor"]["reduced_precision"] = {
+                "dtype": "bf16", "value": round(32 / ems16 * 1e3, 1), "ms_per_batch": round(ems16, 2),
+                "achieved_tflops": round(gflop * 32 / ems16, 2), "peak_tflops": PEAK_BF16_TFLOPS,
+                "frac": round(gflop * 32 / ems16 / PEAK_BF16_TFLOPS, 4), "speedup_over_f32": round(ems / ems16, 2),
+                "note": "bfloat16 operands (weights, activations between layers), f32 accumulation, f32 output; "
+                        "[mi355x].extractor_dtype = \"bfloat16\""}
+        except (ValueError, NotImplementedError) as e:  # a backbone without a 16-bit path says so
+            out["extractor"]["reduced_precision"] = {"dtype": "bf16", "value": None, "note": str(e)}
+        del imgs
 
     if cpu is not None:
         v = cpu["pairs_per_s"]

@@ -64,6 +64,8 @@ SIGNATURES = {
     "spr_rgb_to_lab_u8": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "spr_lab_to_rgb_u8": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "spr_vgg_plan_create": (C.c_int, [_I32, _I32, C.POINTER(_VP)]),
+    "spr_vgg_plan_create_ex": (C.c_int, [_I32, _I32, _I32, C.POINTER(_VP)]),
+    "spr_vgg_plan_compute": (C.c_int, [_VP]),
     "spr_vgg_conv_info": (C.c_int, [_VP, _I32, C.POINTER(_I32), C.POINTER(_I32)]),
     "spr_vgg16_plan_create": (C.c_int, [_I32, C.POINTER(_VP)]),
     "spr_vgg16_plan_destroy": (None, [_VP]),

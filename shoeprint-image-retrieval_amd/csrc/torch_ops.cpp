@@ -61,7 +61,7 @@ int method_code(const std::string& m) {
 std::mutex g_mutex;
 using NccKey = std::tuple<int, int, int, int, int, int, int, int, int>;  // device, C, qh, qw, gh, gw, crop, dtype, method
 std::map<NccKey, spr_ncc_plan*> g_ncc_plans;
-std::map<std::tuple<int, int, int>, spr_vgg16_plan*> g_vgg_plans;  // device, arch, block
+std::map<std::tuple<int, int, int, int>, spr_vgg16_plan*> g_vgg_plans;  // device, arch, block, compute type
 
 spr_ncc_plan* ncc_plan(int device, int c, int qh, int qw, int gh, int gw, int crop, int dtype, int method) {
   std::lock_guard<std::mutex> lock(g_mutex);
@@ -137,9 +137,10 @@ at::Tensor ranks(const at::Tensor& scores, const at::Tensor& match) {
 
 // features[:block] of a plain VGG (arch 0 VGG16, 1 VGG19, 2 VGG19_BN; network.py:121-139, :185-186) on a uint8 batch
 // [N,H,W] (grey, repeated over three planes: network.py:67) or [N,H,W,3]; `packed` = the weights as spr_vgg16_pack_weights
-// wrote them; mean / std as the reference's transforms take them (network.py:60-71).  float32 [N,C,h,w] out.
+// wrote them; mean / std as the reference's transforms take them (network.py:60-71); compute = spr_dtype of the plan
+// (spr_vgg_plan_create_ex: 0 the exact f32 matrix cores, 1 / 2 float16 / bfloat16 operands).  float32 [N,C,h,w] out.
 at::Tensor extract(const at::Tensor& images, const at::Tensor& packed, int64_t arch, int64_t block, std::vector<double> mean,
-                   std::vector<double> std_) {
+                   std::vector<double> std_, int64_t compute) {
   check_device_tensor(images, "images");
   check_device_tensor(packed, "packed");
   TORCH_CHECK(images.scalar_type() == at::kByte && (images.dim() == 3 || (images.dim() == 4 && images.size(3) == 3)),
@@ -149,10 +150,12 @@ at::Tensor extract(const at::Tensor& images, const at::Tensor& packed, int64_t a
   spr_vgg16_plan* plan = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_mutex);
-    const auto key = std::make_tuple(static_cast<int>(images.device().index()), static_cast<int>(arch), static_cast<int>(block));
+    const auto key = std::make_tuple(static_cast<int>(images.device().index()), static_cast<int>(arch), static_cast<int>(block),
+                                     static_cast<int>(compute));
     auto it = g_vgg_plans.find(key);
     if (it == g_vgg_plans.end()) {
-      check(spr_vgg_plan_create(static_cast<int32_t>(arch), static_cast<int32_t>(block), &plan), "extract (plan)");
+      check(spr_vgg_plan_create_ex(static_cast<int32_t>(arch), static_cast<int32_t>(block), static_cast<int32_t>(compute), &plan),
+            "extract (plan)");
       g_vgg_plans[key] = plan;
     } else {
       plan = it->second;
@@ -180,7 +183,7 @@ at::Tensor extract(const at::Tensor& images, const at::Tensor& packed, int64_t a
 TORCH_LIBRARY(shoeprint_mi355x, m) {
   m.def("ncc_scores(Tensor q, Tensor g, int crop=2, str method='auto', int max_prepared_bytes=0) -> Tensor");
   m.def("ranks(Tensor scores, Tensor match) -> Tensor");
-  m.def("extract(Tensor images, Tensor packed, int arch, int block, float[] mean, float[] std) -> Tensor");
+  m.def("extract(Tensor images, Tensor packed, int arch, int block, float[] mean, float[] std, int compute=0) -> Tensor");
 }
 
 // Backend-independent registration: the operators check for GPU tensors themselves (there is no CPU kernel to dispatch to).

@@ -36,6 +36,27 @@ constexpr int kCS = 16;         // LDS stride (floats) of one patch pixel / one 
 // 1 % faster, 14 KB less LDS per workgroup).
 __host__ __device__ inline int qoff(int row, int quarter) { return ((quarter ^ ((row >> 2) & 3)) << 2); }
 constexpr int kTN = 64;         // output channels per workgroup
+constexpr int kCk16 = 32;       // 16-bit matrix cores: input channels per chunk = the K of one v_mfma_f32_16x16x32_{bf16,f16}
+
+// Compute types of a plan (spr_vgg_plan_create_ex): the f32 matrix cores (exact, the reference's arithmetic, network.py:235),
+// or 16-bit operands with f32 accumulation - weights and the activations BETWEEN layers rounded to float16 / bfloat16
+// (round to nearest even), bias / ReLU / pool and the last layer's output in f32.
+enum { kF32 = SPR_F32, kF16 = SPR_F16, kBF16 = SPR_BF16 };
+
+__host__ __device__ inline uint16_t round_bf16(float v) {
+  union { float f; uint32_t u; } c;
+  c.f = v;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN
+  c.u += 0x7fffu + ((c.u >> 16) & 1u);                    // round to nearest, ties to even
+  return static_cast<uint16_t>(c.u >> 16);
+}
+__device__ __forceinline__ uint16_t round_f16(float v) {
+  union { _Float16 h; uint16_t u; } c;
+  c.h = static_cast<_Float16>(v);  // v_cvt_f16_f32: round to nearest even
+  return c.u;
+}
+template <int KIND>
+__device__ __forceinline__ uint16_t round16(float v) { return KIND == kF16 ? round_f16(v) : round_bf16(v); }
 
 struct Stage {
   int cin, cout;
@@ -67,12 +88,32 @@ pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ b, fl
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
 
+// 16-bit plans: the MFMA convolutions' weights as [cout/64][cin/32][tap][n:64][c:32] float16 / bfloat16 (64-byte rows: the
+// same bytes per row as the f32 layout, so the LDS image and its swizzle are shared); bias stays f32.
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+pack_weights16_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ packed, size_t w_off,
+                      size_t b_off, int cin, int cout) {
+  uint16_t* dst16 = reinterpret_cast<uint16_t*>(packed + w_off);
+  const size_t total = static_cast<size_t>(cout) * cin * 9;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int tap = static_cast<int>(i % 9);
+    const int c = static_cast<int>((i / 9) % cin);
+    const int n = static_cast<int>(i / (static_cast<size_t>(9) * cin));
+    const int cb = n / kTN, nn = n % kTN, cc = c / kCk16, ci = c % kCk16;
+    dst16[((((static_cast<size_t>(cb) * (cin / kCk16) + cc) * 9 + tap) * kTN + nn) * kCk16) + ci] = round16<KIND>(w[i]);
+  }
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
+}
+
 // ---------------------------------------------------------------- conv1_1 (+ pre-processing)
 // grid = (tiles, n images); out NHWC [n][H][W][64] or NCHW when it is the last stage.
 __global__ void __launch_bounds__(kThreads)
 conv_first_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2,
                   float s0, float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias,
-                  int relu, int nchw, float* __restrict__ out) {
+                  int relu, int nchw, float* __restrict__ out, int kind16) {
+  // kind16 != 0 (16-bit plans, not the last stage): the NHWC activation is stored rounded to float16 / bfloat16
   // Lane = output channel (its 27 weights live in registers), wave = strips of 8 output pixels: a strip reads
   // its 3 x 10 x 3 input values with wave-uniform (broadcast) 16-byte LDS reads and does 216 FMAs on them, and a
   // pixel's 64 channels leave as one 256-byte store.
@@ -133,7 +174,9 @@ conv_first_kernel(const uint8_t* __restrict__ images, int H, int W, int in_chann
       if (y < H && x < W) {
         const float r = relu ? fmaxf(acc[i], 0.0f) : acc[i];
         if (nchw) out[((img * 64 + n) * H + y) * static_cast<size_t>(W) + x] = r;
-        else out[((img * H + y) * static_cast<size_t>(W) + x) * 64 + n] = r;
+        else if (kind16 == 0) out[((img * H + y) * static_cast<size_t>(W) + x) * 64 + n] = r;
+        else reinterpret_cast<uint16_t*>(out)[((img * H + y) * static_cast<size_t>(W) + x) * 64 + n] =
+                 kind16 == kF16 ? round_f16(r) : round_bf16(r);
       }
     }
   }
@@ -282,6 +325,148 @@ conv_mfma_kernel(const float* __restrict__ in, int H, int W, int cin, int cout, 
   }
 }
 
+// ---------------------------------------------------------------- 3x3 conv on the 16-bit matrix cores
+// The same implicit GEMM, tile and LDS image as conv_mfma_kernel with 32 input channels per chunk: a pixel's 64-byte LDS
+// row now holds 32 float16 / bfloat16 channels, and the 16-byte quarter a lane reads (8 channels) is exactly its operand
+// of ONE v_mfma_f32_16x16x32 (lane (p, q): A row p = pixel, k = 8q .. 8q + 7; B column p = output channel, same k).  The
+// matrix work per chunk is 16 x shorter than on the f32 cores while the bytes staged are the same, so BOTH the input patch
+// and the filter slab of the next chunk are requested into registers before the MFMA loop of the current one.
+// in: NHWC 16-bit; out: NHWC 16-bit (rounded, the next layer's operand) or, for the last layer, NCHW float32.
+template <int KIND>
+__global__ void __launch_bounds__(kThreads, 2)
+conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, const uint16_t* __restrict__ wts,
+              const float* __restrict__ bias, int relu, int pool, int nchw, float* __restrict__ out,
+              float* __restrict__ tap) {
+  unsigned char* lds = dyn_lds();
+  float* patch = reinterpret_cast<float*>(lds);  // [18*18][16 dwords]: dword = two channels
+  float* wl = patch + kPatch * kPatch * kCS;     // [9*64][16 dwords]
+  const int tiles_x = ceil_div(W, kTile);
+  const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
+  const int y0 = ty * kTile, x0 = tx * kTile;
+  const int cb = static_cast<int>(blockIdx.y);
+  const size_t img = blockIdx.z;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int p = lane & 15, q = lane >> 4;
+  const int nchunks = cin / kCk16;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint16_t* in_img = in + img * static_cast<size_t>(H) * W * cin;
+  constexpr int kPatchPieces = kPatch * kPatch * 4, kFilterPieces = 9 * kTN * 4;
+  constexpr int kPP = (kPatchPieces + kThreads - 1) / kThreads, kFP = kFilterPieces / kThreads;
+  float4 pre_p[kPP], pre_f[kFP];
+  auto request = [&](int cc) {
+#pragma unroll
+    for (int k = 0; k < kPP; ++k) {
+      const int i = tid + k * kThreads;
+      const int pp = i >> 2, qq = i & 3;
+      const int y = y0 - 1 + pp / kPatch, x = x0 - 1 + pp % kPatch;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < kPatchPieces && y >= 0 && y < H && x >= 0 && x < W)
+        v = *reinterpret_cast<const float4*>(in_img + (static_cast<size_t>(y) * W + x) * cin + cc * kCk16 + qq * 8);
+      pre_p[k] = v;
+    }
+    const uint16_t* wsrc = wts + (static_cast<size_t>(cb) * nchunks + cc) * (9 * kTN * kCk16);
+#pragma unroll
+    for (int k = 0; k < kFP; ++k) {
+      const int i = tid + k * kThreads;
+      pre_f[k] = *reinterpret_cast<const float4*>(wsrc + (i >> 2) * kCk16 + (i & 3) * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < kPP; ++k) {
+      const int i = tid + k * kThreads;
+      if (i < kPatchPieces) *reinterpret_cast<float4*>(patch + (i >> 2) * kCS + qoff(i >> 2, i & 3)) = pre_p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kFP; ++k) {
+      const int i = tid + k * kThreads;
+      *reinterpret_cast<float4*>(wl + (i >> 2) * kCS + qoff(i >> 2, i & 3)) = pre_f[k];
+    }
+  };
+  request(0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // the previous chunk's fragments are consumed
+    commit();
+    __syncthreads();
+    if (cc + 1 < nchunks) request(cc + 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t % 3;
+      u32x4 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a[i] = *reinterpret_cast<const u32x4*>(patch + ((wave * 4 + i + dy) * kPatch + (p + dx)) * kCS +
+                                               qoff((wave * 4 + i + dy) * kPatch + (p + dx), q));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        b[j] = *reinterpret_cast<const u32x4*>(wl + ((t * kTN) + j * 16 + p) * kCS + qoff((t * kTN) + j * 16 + p, q));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = KIND == kF16 ? mfma_f16_16x16x32(a[i], b[j], acc[i][j]) : mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: as conv_mfma_kernel (the C/D map of the two MFMA shapes is the same); 16-bit NHWC stores are rounded
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = cb * kTN + j * 16 + p;
+    const float bv = bias[ch];
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float t = acc[i][j][jj] + bv;
+        v[i][jj] = relu ? fmaxf(t, 0.0f) : t;
+      }
+    if (tap) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int y = y0 + 4 * wave + i, x = x0 + 4 * q + jj;
+          if (y < H && x < W) tap[((img * cout + ch) * H + y) * static_cast<size_t>(W) + x] = v[i][jj];
+        }
+    }
+    if (pool) {
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+          const float m = fmaxf(fmaxf(v[2 * i2][2 * j2], v[2 * i2][2 * j2 + 1]),
+                                fmaxf(v[2 * i2 + 1][2 * j2], v[2 * i2 + 1][2 * j2 + 1]));
+          const int y = (y0 + 4 * wave) / 2 + i2, x = (x0 + 4 * q) / 2 + j2;
+          if (y < Ho && x < Wo) {
+            if (nchw) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = m;
+            else out16[((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + ch] = round16<KIND>(m);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int y = y0 + 4 * wave + i, x = x0 + 4 * q + jj;
+          if (y < Ho && x < Wo) {
+            if (nchw) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = v[i][jj];
+            else out16[((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + ch] = round16<KIND>(v[i][jj]);
+          }
+        }
+    }
+  }
+}
+
 constexpr size_t kConvLds = sizeof(float) * (kPatch * kPatch * kCS + 9 * kTN * kCS);
 
 }  // namespace
@@ -289,6 +474,7 @@ constexpr size_t kConvLds = sizeof(float) * (kPatch * kPatch * kCS + 9 * kTN * k
 
 struct spr_vgg16_plan {
   int block;
+  int compute;  // SPR_F32 (f32 matrix cores, exact) | SPR_F16 | SPR_BF16 (16-bit operands, f32 accumulation)
   std::vector<spr::Stage> stages;
   std::vector<int> feature_index;  // position of every convolution in model.features
   std::vector<int> bn_inside;      // 1: its BatchNorm2d lies inside features[:block] (folded by the host)
@@ -301,8 +487,18 @@ using namespace spr;
 // and its ReLU.  BatchNorm in eval mode is an affine map per channel: the host folds it into the convolution's
 // weights and bias when the layer lies inside features[:block], so the kernels never see it.
 extern "C" int spr_vgg_plan_create(int32_t arch, int32_t block, spr_vgg16_plan** plan_out) {
+  return spr_vgg_plan_create_ex(arch, block, SPR_F32, plan_out);
+}
+
+extern "C" int spr_vgg_plan_compute(const spr_vgg16_plan* plan) { return plan ? plan->compute : SPR_ERR_ARG; }
+
+extern "C" int spr_vgg_plan_create_ex(int32_t arch, int32_t block, int32_t compute, spr_vgg16_plan** plan_out) {
   if (!plan_out) { set_error("spr_vgg_plan_create: null pointer"); return SPR_ERR_ARG; }
   *plan_out = nullptr;
+  if (compute != SPR_F32 && compute != SPR_F16 && compute != SPR_BF16) {
+    set_error("spr_vgg_plan_create_ex: compute type %d (SPR_F32 | SPR_F16 | SPR_BF16)", compute);
+    return SPR_ERR_ARG;
+  }
   static const int cfg_d[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -1, 512, 512, 512, -1, 512, 512, 512, -1};
   static const int cfg_e[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, 256, -1,
                               512, 512, 512, 512, -1, 512, 512, 512, 512, -1};
@@ -332,6 +528,7 @@ extern "C" int spr_vgg_plan_create(int32_t arch, int32_t block, spr_vgg16_plan**
   spr_vgg16_plan* plan = new (std::nothrow) spr_vgg16_plan();
   if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
   plan->block = block;
+  plan->compute = compute;
   size_t off = 0;
   for (int i = 0; i < block; ++i) {
     if (ops[i].kind != 'C') continue;  // B is folded by the host, R and P are fused into the preceding convolution
@@ -342,7 +539,8 @@ extern "C" int spr_vgg_plan_create(int32_t arch, int32_t block, spr_vgg16_plan**
     if (has_bn) ++j;
     s.relu = (j < block && ops[j].kind == 'R') ? 1 : 0;
     s.pool = (s.relu && j + 1 < block && ops[j + 1].kind == 'P') ? 1 : 0;
-    s.w_off = off; off += static_cast<size_t>(s.cout) * s.cin * 9;
+    // (16-bit plans: two weights per float slot, except the first convolution, which stays a plain f32 FMA kernel)
+    s.w_off = off; off += static_cast<size_t>(s.cout) * s.cin * 9 / ((compute != SPR_F32 && s.cin != 3) ? 2 : 1);
     s.b_off = off; off += static_cast<size_t>(s.cout);
     off = (off + 3) / 4 * 4;  // keep every slab 16-byte aligned
     plan->stages.push_back(s);
@@ -410,8 +608,16 @@ extern "C" int spr_vgg16_pack_weights(spr_vgg16_plan* plan, const float* const* 
   for (size_t i = 0; i < plan->stages.size(); ++i) {
     const Stage& s = plan->stages[i];
     if (!weights[i] || !biases[i]) { set_error("spr_vgg16_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(256), dim3(kThreads), 0, static_cast<hipStream_t>(stream), weights[i],
-                       biases[i], static_cast<float*>(packed), s.w_off, s.b_off, s.cin, s.cout, i == 0 ? 1 : 0);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (i > 0 && plan->compute == SPR_F16)
+      hipLaunchKernelGGL(pack_weights16_kernel<kF16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), s.w_off, s.b_off, s.cin, s.cout);
+    else if (i > 0 && plan->compute == SPR_BF16)
+      hipLaunchKernelGGL(pack_weights16_kernel<kBF16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), s.w_off, s.b_off, s.cin, s.cout);
+    else
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(256), dim3(kThreads), 0, hs, weights[i],
+                         biases[i], static_cast<float*>(packed), s.w_off, s.b_off, s.cin, s.cout, i == 0 ? 1 : 0);
     const int rc = check_launch("pack_weights_kernel");
     if (rc != SPR_OK) return rc;
   }
@@ -434,7 +640,7 @@ extern "C" size_t spr_vgg16_workspace_bytes(const spr_vgg16_plan* plan, int64_t 
     if (f > biggest) biggest = f;
     if (s.pool) { h /= 2; w /= 2; }
   }
-  return 2 * align_up(biggest * sizeof(float), 256);
+  return 2 * align_up(biggest * (plan->compute == SPR_F32 ? sizeof(float) : sizeof(uint16_t)), 256);
 }
 
 static int vgg_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
@@ -466,6 +672,10 @@ static int vgg_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, i
                    reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + half)};
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(kConvLds));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<kF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kConvLds));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<kBF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kConvLds));
   int h = in_h, w = in_w;
   const float* cur = nullptr;
   for (size_t i = 0; i < plan->stages.size(); ++i) {
@@ -479,8 +689,20 @@ static int vgg_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, i
     if (i == 0) {
       hipLaunchKernelGGL(conv_first_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, h, w,
                          in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2],
-                         pk + st.w_off, pk + st.b_off, st.relu, last ? 1 : 0, dst);
+                         pk + st.w_off, pk + st.b_off, st.relu, last ? 1 : 0, dst, plan->compute == SPR_F32 ? 0 : plan->compute);
       const int rc = check_launch("conv_first_kernel");
+      if (rc != SPR_OK) return rc;
+    } else if (plan->compute != SPR_F32) {
+      const dim3 grid(tiles, static_cast<unsigned>(st.cout / kTN), static_cast<unsigned>(n));
+      const uint16_t* src16 = reinterpret_cast<const uint16_t*>(cur);
+      const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + st.w_off);
+      if (plan->compute == SPR_F16)
+        hipLaunchKernelGGL(conv16_kernel<kF16>, grid, dim3(kThreads), kConvLds, s, src16, h, w, st.cin, st.cout, w16,
+                           pk + st.b_off, st.relu, st.pool, last ? 1 : 0, dst, tap);
+      else
+        hipLaunchKernelGGL(conv16_kernel<kBF16>, grid, dim3(kThreads), kConvLds, s, src16, h, w, st.cin, st.cout, w16,
+                           pk + st.b_off, st.relu, st.pool, last ? 1 : 0, dst, tap);
+      const int rc = check_launch("conv16_kernel");
       if (rc != SPR_OK) return rc;
     } else {
       hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, static_cast<unsigned>(st.cout / kTN), static_cast<unsigned>(n)),

@@ -56,6 +56,7 @@ _EFFNET_MODELS = {"EfficientNetV2_S": (0, IMAGENET_MEAN, IMAGENET_STD, 1e-3), "E
 _REFERENCE_MODELS = {"EfficientNet_B1", "EfficientNet_B2", "EfficientNet_B3", "EfficientNet_B4",
                      "EfficientNet_B5", "EfficientNet_B7", "EfficientNetV2_S", "EfficientNetV2_M", "EfficientNetV2_L",
                      "DenseNet_201"}
+_COMPUTE = {"float32": _lib.F32, "float16": _lib.F16, "bfloat16": _lib.BF16}
 _warned = False
 
 
@@ -163,7 +164,12 @@ class Model:
                 parameters = self._load_resnet_parameters(config)
             self._set_resnet_parameters(parameters)
             return
-        self.lib.check(self.lib.spr_vgg_plan_create(self.arch, self.block, C.byref(handle)))
+        # [mi355x].extractor_dtype: compute type of the convolutions behind the first ("float32": the f32 matrix cores, exact,
+        # the reference's arithmetic; "bfloat16" / "float16": 16-bit operands, f32 accumulation - BASELINE configs 3 / 5)
+        self.compute = str((config.get("mi355x") or {}).get("extractor_dtype", "float32") or "float32")
+        if self.compute not in _COMPUTE:
+            raise ValueError(f"[mi355x].extractor_dtype = {self.compute!r}: expected one of {sorted(_COMPUTE)}")
+        self.lib.check(self.lib.spr_vgg_plan_create_ex(self.arch, self.block, _COMPUTE[self.compute], C.byref(handle)))
         self.handle = handle
         self.n_convs = self.lib.spr_vgg16_num_convs(handle)
         if parameters is None:
@@ -500,7 +506,7 @@ class Model:
             if _torch_ops.enabled() and images_dev.is_contiguous() and len(shape) == (4 if in_channels == 3 else 3):
                 # the registered PyTorch-ROCm custom op (csrc/torch_ops.cpp): same plan, same kernels, current stream
                 return _torch_ops.load().extract(images_dev, self.packed, self.arch, self.block, [float(m) for m in self.mean],
-                                                 [float(s) for s in self.std])
+                                                 [float(s) for s in self.std], _COMPUTE[self.compute])
         c, oh, ow = self.output_shape(h, w)
         out = dev.empty((n, c, oh, ow), np.float32)
         ws_fn = (self.lib.spr_densenet_workspace_bytes if self.densenet else self.lib.spr_effnet_workspace_bytes if self.effnet else

@@ -29,6 +29,33 @@ def check_block(block, hw, device, lib, n_images=2):
     m.close()
 
 
+# 16-bit compute types (spr_vgg_plan_create_ex; build-defined, BASELINE configs 3 / 5): the oracle takes the SAME rounded
+# weights and rounds the activations at the same places, so what is left is the order of the f32 additions - plus, rarely,
+# an activation whose f32 value sits on a rounding boundary and lands one 16-bit step apart (2^-8 relative for bfloat16,
+# 2^-11 for float16), which the layers behind it spread.  Tolerance, relative to the largest activation:
+TOL16 = {"bfloat16": 4e-3, "float16": 5e-4}
+
+
+def check_block16(block, hw, device, lib, compute, arch="VGG16", n_images=2):
+    cfg = {"model": dict(CFG["model"], type=arch), "comparison": CFG["comparison"], "mi355x": {"extractor_dtype": compute}}
+    m = network.Model(cfg, block, device=device, library=lib)
+    assert m.compute == compute and lib.spr_vgg_plan_compute(m.handle) == {"float16": 1, "bfloat16": 2}[compute]
+    params = synth.vgg_parameters(1234, m.conv_shapes(), [bn for _, bn in m.conv_info()])
+    imgs = np.stack([synth.shoeprint_image(5, i, *hw) for i in range(n_images)])
+    got = device.to_host(m.extract_device(device.to_device(imgs)))
+    assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    exact = []
+    for i in range(n_images):
+        ref = vgg_oracle.get_feature_maps(imgs[i], block, params, arch, compute=compute)
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, atol=TOL16[compute] * max(1.0, np.abs(ref).max()), rtol=0)
+        exact.append(vgg_oracle.get_feature_maps(imgs[i], block, params, arch))
+    # and the 16-bit features stay close to the float32 network's (a sanity bound, not a parity claim)
+    e = np.stack(exact)
+    assert np.abs(got - e).max() <= (0.05 if compute == "bfloat16" else 0.01) * max(1.0, np.abs(e).max())
+    m.close()
+
+
 def check_other_vgg(arch, block, hw, device, lib):
     """VGG19 / VGG19_BN truncations (reference network.py:121-139) against the torch-CPU oracle, including cuts
     between a convolution and its BatchNorm and between the BatchNorm and its ReLU."""

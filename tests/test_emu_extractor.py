@@ -27,6 +27,16 @@ def test_emu_other_vgg_backbones(arch, block, hw):
     ec.check_other_vgg(arch, block, hw, HostDevice(), emu_library())
 
 
+@pytest.mark.parametrize("compute,arch,block,hw", [("bfloat16", "VGG16", 5, (36, 40)), ("float16", "VGG16", 10, (40, 36)),
+                                                   ("bfloat16", "VGG16", 3, (17, 33)), ("float16", "VGG19_BN", 14, (24, 24)),
+                                                   ("bfloat16", "VGG16", 2, (18, 20))])
+def test_emu_vgg_16bit_matrix_cores(compute, arch, block, hw):
+    """The extractor on the 16-bit matrix cores (v_mfma_f32_16x16x32_{bf16,f16}; spr_vgg_plan_create_ex) under emulation:
+    truncations ending behind a pool, a ReLU and a bare convolution; a BatchNorm folded before the weights are rounded; a
+    cut (block 2) that leaves only the f32 first layer."""
+    ec.check_block16(block, hw, HostDevice(), emu_library(), compute, arch=arch, n_images=1)
+
+
 def test_emu_resnet50_layer1():
     """The build-defined ResNet50 extractor under emulation: stem, max pool, the three bottlenecks of layer1 (1x1 and 3x3
     implicit GEMMs, downsample branch, residual sums) on a 40x36 image - odd-sized maps after the strided layers."""

@@ -491,3 +491,14 @@ def test_torch_ops_equal_the_ctypes_route_bit_for_bit(lib, monkeypatch):
     with pytest.raises(RuntimeError, match="channel mismatch"):
         ops.ncc_scores(q, g[:, :4].contiguous())
     model.close()
+
+
+@pytest.mark.parametrize("compute,arch,block,hw", [("bfloat16", "VGG16", 16, (512, 256)), ("float16", "VGG16", 16, (512, 256)),
+                                                   ("bfloat16", "VGG16", 30, (128, 96)), ("float16", "VGG19_BN", 27, (96, 64)),
+                                                   ("bfloat16", "VGG16", 7, (50, 38))])
+def test_vgg_on_the_16bit_matrix_cores(torch_dev, lib, compute, arch, block, hw):
+    """spr_vgg_plan_create_ex(SPR_BF16 / SPR_F16): features[:block] with 16-bit operands and f32 accumulation against the
+    torch-CPU oracle on the SAME rounded weights and activations (tolerance stated in extractor_cases.TOL16)."""
+    import extractor_cases as ec
+
+    ec.check_block16(block, hw, torch_dev, lib, compute, arch=arch, n_images=1 if hw[0] >= 512 else 2)
