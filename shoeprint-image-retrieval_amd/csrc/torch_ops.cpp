@@ -10,7 +10,6 @@
 // shape class for the life of the process.  Nothing synchronises.
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 #include <torch/library.h>
@@ -32,6 +31,20 @@ void check(int rc, const char* what) {
 spr_stream_t current_stream(const at::Tensor& t) {
   return static_cast<spr_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
 }
+
+// Makes the tensor's GPU the current HIP device for the call (plans allocate, kernels launch on the current device).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(const at::Device& d) {
+    TORCH_CHECK(hipGetDevice(&prev) == hipSuccess, "hipGetDevice failed");
+    if (prev != d.index()) {
+      TORCH_CHECK(hipSetDevice(d.index()) == hipSuccess, "hipSetDevice(", int(d.index()), ") failed");
+    } else {
+      prev = -1;
+    }
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 void check_device_tensor(const at::Tensor& t, const char* name) {
   TORCH_CHECK(t.device().is_cuda(), name, " must live in HBM (a GPU tensor); there is no CPU path");  // torch calls the ROCm device type "cuda"
@@ -83,7 +96,7 @@ at::Tensor ncc_scores(const at::Tensor& q, const at::Tensor& g, int64_t crop, st
   TORCH_CHECK(q.dim() == 4 && g.dim() == 4, "q and g are [N, C, h, w] batches");
   TORCH_CHECK(q.size(1) == g.size(1), "channel mismatch: queries ", q.size(1), ", gallery ", g.size(1));
   TORCH_CHECK(q.scalar_type() == g.scalar_type() && q.device() == g.device(), "q and g must share storage type and device");
-  const c10::hip::HIPGuard guard(q.device());
+  const DeviceGuard guard(q.device());
   const int64_t nq = q.size(0), ng = g.size(0);
   at::Tensor scores = at::zeros({nq, ng}, q.options().dtype(at::kFloat));
   if (nq == 0 || ng == 0) return scores;
@@ -127,7 +140,7 @@ at::Tensor ranks(const at::Tensor& scores, const at::Tensor& match) {
   check_device_tensor(match, "match");
   TORCH_CHECK(scores.dim() == 2 && scores.scalar_type() == at::kFloat, "scores is a float32 [Q, G] matrix");
   TORCH_CHECK(match.dim() == 1 && match.scalar_type() == at::kInt && match.size(0) == scores.size(0), "match is int32 [Q]");
-  const c10::hip::HIPGuard guard(scores.device());
+  const DeviceGuard guard(scores.device());
   at::Tensor out = at::zeros({scores.size(0)}, match.options());
   if (scores.size(0) == 0) return out;
   check(spr_rank_true_match(scores.data_ptr<float>(), scores.size(1), scores.size(0), scores.size(1), match.data_ptr<int32_t>(),
@@ -146,7 +159,7 @@ at::Tensor extract(const at::Tensor& images, const at::Tensor& packed, int64_t a
   TORCH_CHECK(images.scalar_type() == at::kByte && (images.dim() == 3 || (images.dim() == 4 && images.size(3) == 3)),
               "images are uint8 [N, H, W] or [N, H, W, 3]");
   TORCH_CHECK(mean.size() == 3 && std_.size() == 3, "mean and std hold three values");
-  const c10::hip::HIPGuard guard(images.device());
+  const DeviceGuard guard(images.device());
   spr_vgg16_plan* plan = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_mutex);
