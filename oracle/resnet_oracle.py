@@ -33,15 +33,30 @@ def conv_specs(block: int):
     return specs
 
 
-def _cbn(x, p, stride, pad):
-    w, b, gamma, beta, mu, var = (torch.from_numpy(np.asarray(t, dtype=np.float32)) for t in p)
-    x = F.conv2d(x, w, b, stride=stride, padding=pad)
-    return F.batch_norm(x, mu, var, gamma, beta, training=False, eps=1e-5)
+def _round(x: torch.Tensor, compute: str | None) -> torch.Tensor:
+    if not compute:
+        return x
+    return x.to({"float16": torch.float16, "bfloat16": torch.bfloat16}[compute]).to(torch.float32)
 
 
-def get_feature_maps(img: np.ndarray, block: int, parameters) -> np.ndarray:
+def _cbn(x, p, stride, pad, compute=None):
+    w, b, gamma, beta, mu, var = (np.asarray(t, dtype=np.float32) for t in p)
+    if compute:
+        # 16-bit plans: the library folds the BatchNorm into the convolution in float32, THEN rounds the weights; the operand is
+        # a stored (rounded) activation; sums, bias in float32
+        scale = gamma / np.sqrt(var + np.float32(1e-5))
+        w = _round(torch.from_numpy(np.ascontiguousarray(w * scale[:, None, None, None])), compute)
+        return F.conv2d(_round(x, compute), w, torch.from_numpy(np.ascontiguousarray((b - mu) * scale + beta)), stride=stride, padding=pad)
+    x = F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=pad)
+    return F.batch_norm(x, torch.from_numpy(mu), torch.from_numpy(var), torch.from_numpy(gamma), torch.from_numpy(beta),
+                        training=False, eps=1e-5)
+
+
+def get_feature_maps(img: np.ndarray, block: int, parameters, compute: str | None = None) -> np.ndarray:
     """uint8 [H,W] (already CLAHE'd) -> float32 [C,h,w]; parameters[i] = (w, b, gamma, beta, running_mean, running_var)
-    of convolution i of conv_specs(block) and its BatchNorm."""
+    of convolution i of conv_specs(block) and its BatchNorm.  ``compute`` = "float16" | "bfloat16": the 16-bit compute type of
+    spr_resnet_plan_create_ex - every convolution behind the stem takes rounded weights and a rounded operand, the residual
+    operand is a rounded stored activation, everything else float32."""
     x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None].repeat(3, 1, 1)
     mean = torch.tensor(MEAN, dtype=torch.float32)[:, None, None]
     std = torch.tensor(STD, dtype=torch.float32)[:, None, None]
@@ -53,10 +68,10 @@ def get_feature_maps(img: np.ndarray, block: int, parameters) -> np.ndarray:
         i = 1
         while i < len(specs):
             down = i + 3 < len(specs) and specs[i + 3][4] == 4
-            y = F.relu(_cbn(x, parameters[i], 1, 0))
-            y = F.relu(_cbn(y, parameters[i + 1], specs[i + 1][3], 1))
-            y = _cbn(y, parameters[i + 2], 1, 0)
-            idn = _cbn(x, parameters[i + 3], specs[i + 3][3], 0) if down else x
-            x = F.relu(y + idn)
+            y = F.relu(_cbn(x, parameters[i], 1, 0, compute))
+            y = F.relu(_cbn(y, parameters[i + 1], specs[i + 1][3], 1, compute))
+            y = _cbn(y, parameters[i + 2], 1, 0, compute)
+            idn = _cbn(x, parameters[i + 3], specs[i + 3][3], 0, compute) if down else x
+            x = F.relu(y + _round(idn, compute))
             i += 4 if down else 3
     return x.numpy().squeeze(0)

@@ -248,6 +248,199 @@ conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin,
   }
 }
 
+// ---------------------------------------------------------------- implicit-GEMM convolution on the 16-bit matrix cores
+// spr_resnet_plan_create_ex(SPR_F16 | SPR_BF16): the same GEMM view with float16 / bfloat16 operands and f32 accumulation
+// (v_mfma_f32_16x16x32: K = 32 per instruction).  The matrix work per byte staged is 16 x shorter than on the f32 cores, so
+// the tile is larger: workgroup = 128 pixels x 64 channels x a K chunk of 64 (two MFMA k-steps), 4 waves x (32 pixels x 64
+// channels) = 16 MFMAs per wave and chunk; the A tile (128 gathered rows of 64 contiguous channels = 128 bytes each) and the
+// B tile (64 filter rows) are loaded into registers one chunk ahead and written to LDS behind the barrier.  LDS rows are 128
+// bytes = eight 16-byte slots; slot s of row r sits at s ^ ((r >> 1) & 7), so the 16 lanes x 4 k-groups of an operand read
+// fall into different banks.  Activations between layers: NHWC, rounded to the 16-bit type; the residual operand is such a
+// stored activation; bias / residual sum / ReLU in f32; the last layer writes float32 NCHW.
+constexpr int kHM = 128, kHN = 64, kHK = 64;
+constexpr int kHRowDw = 32;  // dwords per LDS row (128 bytes)
+
+__host__ __device__ inline uint16_t rround_bf16(float v) {
+  union { float f; uint32_t u; } c;
+  c.f = v;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  c.u += 0x7fffu + ((c.u >> 16) & 1u);
+  return static_cast<uint16_t>(c.u >> 16);
+}
+template <int KIND>
+__device__ __forceinline__ uint16_t rround16(float v) {
+  if (KIND == SPR_F16) {
+    union { _Float16 h; uint16_t u; } c;
+    c.h = static_cast<_Float16>(v);
+    return c.u;
+  }
+  return rround_bf16(v);
+}
+template <int KIND>
+__device__ __forceinline__ float rvalue16(uint16_t b) {
+  if (KIND == SPR_F16) {
+    union { uint16_t u; _Float16 h; } c;
+    c.u = b;
+    return static_cast<float>(c.h);
+  }
+  union { uint32_t u; float f; } c;
+  c.u = static_cast<uint32_t>(b) << 16;
+  return c.f;
+}
+
+// GEMM convs of a 16-bit plan: [cout/64][K/64][n:64][k:64] float16 / bfloat16, K index = tap * cin + c; bias f32
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+rpack16_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ packed, size_t w_off,
+               size_t b_off, int cin, int cout, int ks) {
+  uint16_t* dst16 = reinterpret_cast<uint16_t*>(packed + w_off);
+  const int taps = ks * ks;
+  const size_t total = static_cast<size_t>(cout) * cin * taps;
+  const int chunks = taps * cin / kHK;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int tap = static_cast<int>(i % taps);
+    const int c = static_cast<int>((i / taps) % cin);
+    const int n = static_cast<int>(i / (static_cast<size_t>(taps) * cin));
+    const int k = tap * cin + c;
+    dst16[((static_cast<size_t>(n / kHN) * chunks + k / kHK) * kHN + n % kHN) * kHK + k % kHK] = rround16<KIND>(w[i]);
+  }
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
+}
+
+// 3x3 / stride 2 / pad 1 max pool of the stem's f32 NHWC output into the 16-bit NHWC tensor layer1 reads
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+maxpool3_16_kernel(const float* __restrict__ in, int H, int W, int C, uint16_t* __restrict__ out, size_t total) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C);
+    size_t p = i / C;
+    const int ox = static_cast<int>(p % Wo); p /= Wo;
+    const int oy = static_cast<int>(p % Ho);
+    const size_t img = p / Ho;
+    float m = -3.402823466e38f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y = 2 * oy + dy, x = 2 * ox + dx;
+        if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, in[((img * H + y) * static_cast<size_t>(W) + x) * C + c]);
+      }
+    out[i] = rround16<KIND>(m);
+  }
+}
+
+// grid = (ceil(M / 128), cout / 64).  in / res / out: NHWC 16-bit with cin / cout channels; out32: float32 NCHW (last layer)
+template <int KS, int STRIDE, int KIND>
+__global__ void __launch_bounds__(kThreads, 3)
+conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int cin, int cout,
+                   const uint16_t* __restrict__ wts, const float* __restrict__ bias, const uint16_t* __restrict__ res,
+                   int relu, uint16_t* __restrict__ out, float* __restrict__ out32) {
+  __shared__ __attribute__((aligned(16))) uint32_t A[kHM * kHRowDw];
+  __shared__ __attribute__((aligned(16))) uint32_t B[kHN * kHRowDw];
+  constexpr int PAD = KS / 2;
+  const int Ho = (H + 2 * PAD - KS) / STRIDE + 1, Wo = (W + 2 * PAD - KS) / STRIDE + 1;
+  const long long M = static_cast<long long>(n_img) * Ho * Wo;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int p = lane & 15, q = lane >> 4;
+  const int cb = static_cast<int>(blockIdx.y);
+  const long long m0 = static_cast<long long>(blockIdx.x) * kHM;
+  const int cchunks = cin / kHK, chunks = KS * KS * cchunks;
+
+  // staging role: 16-byte slot `ss` of rows sr + 32 k (A: k = 0..3, B: k = 0, 1)
+  const int sr = tid >> 3, ss = tid & 7;
+  int ay[4], ax[4];
+  long long abase[4];  // element offset of pixel (img, 0, 0); negative marks a row beyond M
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long pm = m0 + sr + 32 * k;
+    if (pm < M) {
+      const int px = static_cast<int>(pm % Wo), py = static_cast<int>((pm / Wo) % Ho);
+      const long long pimg = pm / (static_cast<long long>(Wo) * Ho);
+      ay[k] = py * STRIDE - PAD; ax[k] = px * STRIDE - PAD;
+      abase[k] = pimg * H * static_cast<long long>(W) * cin;
+    } else {
+      ay[k] = ax[k] = 0; abase[k] = -1;
+    }
+  }
+  const uint16_t* wbase = wts + static_cast<size_t>(cb) * chunks * (kHN * kHK) + sr * kHK + ss * 8;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[4], rb[2];
+  auto request = [&](int ch) {
+    const int tap = ch / cchunks, cc = ch - tap * cchunks;
+    const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = ay[k] + dy, x = ax[k] + dx;
+      ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (abase[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
+        ra[k] = *reinterpret_cast<const float4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      rb[k] = *reinterpret_cast<const float4*>(wbase + (static_cast<size_t>(ch) * kHN + 32 * k) * kHK);
+  };
+  auto slot = [](int row, int s) { return (s ^ ((row >> 1) & 7)) << 2; };  // dword offset of 16-byte slot s inside row `row`
+  request(0);
+  for (int ch = 0; ch < chunks; ++ch) {
+    __syncthreads();  // the previous chunk's fragments are consumed
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[k];
+    __syncthreads();
+    if (ch + 1 < chunks) request(ch + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + p;
+        a[i] = *reinterpret_cast<const u32x4*>(A + row * kHRowDw + slot(row, ks * 4 + q));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = j * 16 + p;
+        b[j] = *reinterpret_cast<const u32x4*>(B + row * kHRowDw + slot(row, ks * 4 + q));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = KIND == SPR_F16 ? mfma_f16_16x16x32(a[i], b[j], acc[i][j]) : mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+    }
+  }
+  // ---- epilogue: lane (q, p) owns pixels m0 + 32 wave + 16 i + 4 q + r, channel cb*64 + 16 j + p
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wave * 32 + i * 16 + 4 * q + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = cb * kHN + j * 16 + p;
+        float v = acc[i][j][r] + bias[ch];
+        if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + ch]);
+        if (relu) v = fmaxf(v, 0.0f);
+        if (out32) {
+          const int ox = static_cast<int>(m % Wo), oy = static_cast<int>((m / Wo) % Ho);
+          const size_t img = static_cast<size_t>(m / (static_cast<long long>(Wo) * Ho));
+          out32[((img * cout + ch) * Ho + oy) * static_cast<size_t>(Wo) + ox] = v;
+        } else {
+          out[static_cast<size_t>(m) * cout + ch] = rround16<KIND>(v);
+        }
+      }
+    }
+}
+
 // ================================================================ EfficientNetV2 (network.py:163-175) building blocks
 // Activations NHWC float32 with the channel count padded to a multiple of 64 (the GEMM tile; padded channels hold zeros:
 // zero weights and biases, SiLU(0) = 0); eval-mode BatchNorm folded into the convolutions by the host.
@@ -370,6 +563,7 @@ dnet_out_kernel(const float* __restrict__ in, int HW, int C, int ld, const float
 
 struct spr_resnet_plan {
   int block;                       // top-level children kept: 5 = layer1, 6 = layer2, 7 = layer3
+  int compute;                     // SPR_F32 (exact) | SPR_F16 | SPR_BF16 (16-bit operands, f32 accumulation)
   std::vector<spr::RConv> convs;   // in torchvision's module order (conv1; per bottleneck conv1, conv2, conv3, [downsample])
   size_t packed_floats;
 };
@@ -377,8 +571,18 @@ struct spr_resnet_plan {
 using namespace spr;
 
 extern "C" int spr_resnet_plan_create(int32_t block, spr_resnet_plan** plan_out) {
+  return spr_resnet_plan_create_ex(block, SPR_F32, plan_out);
+}
+
+extern "C" int spr_resnet_plan_compute(const spr_resnet_plan* plan) { return plan ? plan->compute : SPR_ERR_ARG; }
+
+extern "C" int spr_resnet_plan_create_ex(int32_t block, int32_t compute, spr_resnet_plan** plan_out) {
   if (!plan_out) { set_error("spr_resnet_plan_create: null pointer"); return SPR_ERR_ARG; }
   *plan_out = nullptr;
+  if (compute != SPR_F32 && compute != SPR_F16 && compute != SPR_BF16) {
+    set_error("spr_resnet_plan_create_ex: compute type %d (SPR_F32 | SPR_F16 | SPR_BF16)", compute);
+    return SPR_ERR_ARG;
+  }
   if (block < 5 || block > 7) {
     set_error("spr_resnet_plan_create: block %d: the truncation must end after layer1 (5), layer2 (6) or layer3 (7)", block);
     return SPR_ERR_ARG;
@@ -386,11 +590,13 @@ extern "C" int spr_resnet_plan_create(int32_t block, spr_resnet_plan** plan_out)
   spr_resnet_plan* plan = new (std::nothrow) spr_resnet_plan();
   if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
   plan->block = block;
+  plan->compute = compute;
   size_t off = 0;
   auto add = [&](int cin, int cout, int ks, int stride, int relu, int res, int role) {
     RConv c{};
     c.cin = cin; c.cout = cout; c.ks = ks; c.stride = stride; c.relu = relu; c.res = res; c.role = role;
-    c.w_off = off; off += static_cast<size_t>(cout) * cin * ks * ks;
+    // (16-bit plans: two weights per float slot, except the stem, which stays a plain f32 FMA kernel)
+    c.w_off = off; off += static_cast<size_t>(cout) * cin * ks * ks / ((compute != SPR_F32 && role != 0) ? 2 : 1);
     c.b_off = off; off += static_cast<size_t>(cout);
     off = (off + 3) / 4 * 4;
     plan->convs.push_back(c);
@@ -460,8 +666,16 @@ extern "C" int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const
   for (size_t i = 0; i < plan->convs.size(); ++i) {
     const RConv& c = plan->convs[i];
     if (!weights[i] || !biases[i]) { set_error("spr_resnet_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
-    hipLaunchKernelGGL(rpack_kernel, dim3(256), dim3(kThreads), 0, static_cast<hipStream_t>(stream), weights[i], biases[i],
-                       static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks, i == 0 ? 1 : 0);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (i > 0 && plan->compute == SPR_F16)
+      hipLaunchKernelGGL(rpack16_kernel<SPR_F16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks);
+    else if (i > 0 && plan->compute == SPR_BF16)
+      hipLaunchKernelGGL(rpack16_kernel<SPR_BF16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks);
+    else
+      hipLaunchKernelGGL(rpack_kernel, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks, i == 0 ? 1 : 0);
     const int rc = check_launch("rpack_kernel");
     if (rc != SPR_OK) return rc;
   }
@@ -470,10 +684,73 @@ extern "C" int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const
 
 // four activation buffers (block input, two bottleneck intermediates / the downsample branch, block output), each as
 // large as the largest tensor between layers: the stem's output
+static size_t resnet_big16_bytes(int64_t n, int in_h, int in_w) {  // layer1's output, the largest 16-bit tensor
+  const int hp = ((in_h + 1) / 2 + 1) / 2, wp = ((in_w + 1) / 2 + 1) / 2;
+  return align_up(static_cast<size_t>(n) * hp * wp * 256 * sizeof(uint16_t), 256);
+}
 extern "C" size_t spr_resnet_workspace_bytes(const spr_resnet_plan* plan, int64_t n, int32_t in_h, int32_t in_w) {
   if (!plan || n < 0) return 0;
   const size_t stem = static_cast<size_t>(n) * ((in_h + 1) / 2) * ((in_w + 1) / 2) * 64;
+  // 16-bit plans: the stem's f32 tensor, then four 16-bit activation buffers
+  if (plan->compute != SPR_F32) return align_up(stem * sizeof(float), 256) + 4 * resnet_big16_bytes(n, in_h, in_w);
   return 4 * align_up(stem * sizeof(float), 256);
+}
+
+template <int KS, int STRIDE>
+static int launch_gemm16(int kind, const RConv& c, const uint16_t* in, int64_t n, int h, int w, const float* pk,
+                         const uint16_t* res, uint16_t* out, float* out32, hipStream_t s) {
+  const int pad = KS / 2;
+  const int ho = (h + 2 * pad - KS) / STRIDE + 1, wo = (w + 2 * pad - KS) / STRIDE + 1;
+  const long long m = static_cast<long long>(n) * ho * wo;
+  const dim3 grid(static_cast<unsigned>((m + kHM - 1) / kHM), static_cast<unsigned>(c.cout / kHN));
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + c.w_off);
+  if (kind == SPR_F16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, SPR_F16>), grid, dim3(kThreads), 0, s, in,
+                       static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, SPR_BF16>), grid, dim3(kThreads), 0, s, in,
+                       static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32);
+  return check_launch("conv_gemm16_kernel");
+}
+
+// the bottlenecks of a 16-bit plan: x (the pooled stem output, 16-bit NHWC) lives in buf[0]; t1 / t2 / y in buf[1..3]
+static int resnet_blocks16(const spr_resnet_plan* plan, int64_t n, int h, int w, const float* pk, uint16_t* const buf[4],
+                           float* out, hipStream_t s) {
+  uint16_t* x = buf[0];
+  uint16_t* t1 = buf[1];
+  uint16_t* t2 = buf[2];
+  uint16_t* y = buf[3];
+  const int kind = plan->compute;
+  size_t i = 1;
+  while (i < plan->convs.size()) {
+    const RConv& c1 = plan->convs[i];
+    const RConv& c2 = plan->convs[i + 1];
+    const RConv& c3 = plan->convs[i + 2];
+    const bool down = c3.res == 2;
+    const bool last = i + (down ? 4 : 3) == plan->convs.size();
+    const int ho = c2.stride == 2 ? (h + 1) / 2 : h, wo = c2.stride == 2 ? (w + 1) / 2 : w;
+    int rc = launch_gemm16<1, 1>(kind, c1, x, n, h, w, pk, nullptr, t1, nullptr, s);
+    if (rc != SPR_OK) return rc;
+    rc = c2.stride == 2 ? launch_gemm16<3, 2>(kind, c2, t1, n, h, w, pk, nullptr, t2, nullptr, s)
+                        : launch_gemm16<3, 1>(kind, c2, t1, n, h, w, pk, nullptr, t2, nullptr, s);
+    if (rc != SPR_OK) return rc;
+    const uint16_t* resid = x;
+    if (down) {
+      const RConv& cd = plan->convs[i + 3];
+      rc = cd.stride == 2 ? launch_gemm16<1, 2>(kind, cd, x, n, h, w, pk, nullptr, t1, nullptr, s)
+                          : launch_gemm16<1, 1>(kind, cd, x, n, h, w, pk, nullptr, t1, nullptr, s);
+      if (rc != SPR_OK) return rc;
+      resid = t1;
+    }
+    rc = launch_gemm16<1, 1>(kind, c3, t2, n, ho, wo, pk, resid, y, last ? out : nullptr, s);
+    if (rc != SPR_OK) return rc;
+    h = ho; w = wo;
+    uint16_t* old = x;
+    x = y;
+    y = old;
+    i += down ? 4 : 3;
+  }
+  return SPR_OK;
 }
 
 template <int KS, int STRIDE>
@@ -501,9 +778,17 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
   if (!images || !mean3 || !inv_std3 || !packed || !out || !workspace) { set_error("spr_resnet_forward: null pointer"); return SPR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* pk = static_cast<const float*>(packed);
-  const size_t quarter = spr_resnet_workspace_bytes(plan, n, in_h, in_w) / 4;
+  const bool f32 = plan->compute == SPR_F32;
+  const size_t quarter = f32 ? spr_resnet_workspace_bytes(plan, n, in_h, in_w) / 4 : 0;
   float* buf[4];
   for (int i = 0; i < 4; ++i) buf[i] = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + i * quarter);
+  uint16_t* b16[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (!f32) {  // [stem f32 tensor][x][t1][t2][y]
+    const size_t stem_bytes = align_up(static_cast<size_t>(n) * ((in_h + 1) / 2) * ((in_w + 1) / 2) * 64 * sizeof(float), 256);
+    buf[1] = static_cast<float*>(workspace);
+    for (int i = 0; i < 4; ++i)
+      b16[i] = reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(workspace) + stem_bytes + i * resnet_big16_bytes(n, in_h, in_w));
+  }
   // stem + max pool
   int h = (in_h + 1) / 2, w = (in_w + 1) / 2;
   {
@@ -516,12 +801,21 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
     if (rc != SPR_OK) return rc;
     const int hp = (h + 1) / 2, wp = (w + 1) / 2;
     const size_t total = static_cast<size_t>(n) * hp * wp * 64;
-    hipLaunchKernelGGL(maxpool3_kernel, dim3(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16))),
-                       dim3(kThreads), 0, s, buf[1], h, w, 64, buf[0], total, 64);
+    const dim3 pgrid(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16)));
+    if (plan->compute == SPR_F32) {
+      hipLaunchKernelGGL(maxpool3_kernel, pgrid, dim3(kThreads), 0, s, buf[1], h, w, 64, buf[0], total, 64);
+    } else {
+      uint16_t* x16 = b16[0];  // the pooled tensor, rounded: layer1's operand
+      if (plan->compute == SPR_F16)
+        hipLaunchKernelGGL(maxpool3_16_kernel<SPR_F16>, pgrid, dim3(kThreads), 0, s, buf[1], h, w, 64, x16, total);
+      else
+        hipLaunchKernelGGL(maxpool3_16_kernel<SPR_BF16>, pgrid, dim3(kThreads), 0, s, buf[1], h, w, 64, x16, total);
+    }
     rc = check_launch("maxpool3_kernel");
     if (rc != SPR_OK) return rc;
     h = hp; w = wp;
   }
+  if (!f32) return resnet_blocks16(plan, n, h, w, pk, b16, out, s);
   // bottlenecks: x = buf[0]
   float* x = buf[0];
   float* t1 = buf[1];

@@ -139,6 +139,14 @@ class Model:
 
             device = TorchDevice()
         self.dev = device
+        # [mi355x].extractor_dtype: compute type of the convolutions behind the first layer ("float32": the f32 matrix cores,
+        # exact, the reference's arithmetic; "bfloat16" / "float16": 16-bit operands, f32 accumulation - BASELINE configs 3 / 5)
+        self.compute = str((config.get("mi355x") or {}).get("extractor_dtype", "float32") or "float32")
+        if self.compute not in _COMPUTE:
+            raise ValueError(f"[mi355x].extractor_dtype = {self.compute!r}: expected one of {sorted(_COMPUTE)}")
+        if self.compute != "float32" and (self.effnet or self.densenet):
+            raise NotImplementedError(f"{model_str}: the 16-bit matrix-core path is built for the VGG and ResNet50 extractors; "
+                                      "use [mi355x].extractor_dtype = \"float32\"")
         handle = C.c_void_p()
         if self.densenet:
             self.lib.check(self.lib.spr_densenet_plan_create(self.block, C.byref(handle)))
@@ -157,18 +165,13 @@ class Model:
             self._set_effnet_parameters(parameters)
             return
         if self.resnet:
-            self.lib.check(self.lib.spr_resnet_plan_create(self.block, C.byref(handle)))
+            self.lib.check(self.lib.spr_resnet_plan_create_ex(self.block, _COMPUTE[self.compute], C.byref(handle)))
             self.handle = handle
             self.n_convs = self.lib.spr_resnet_num_convs(handle)
             if parameters is None:
                 parameters = self._load_resnet_parameters(config)
             self._set_resnet_parameters(parameters)
             return
-        # [mi355x].extractor_dtype: compute type of the convolutions behind the first ("float32": the f32 matrix cores, exact,
-        # the reference's arithmetic; "bfloat16" / "float16": 16-bit operands, f32 accumulation - BASELINE configs 3 / 5)
-        self.compute = str((config.get("mi355x") or {}).get("extractor_dtype", "float32") or "float32")
-        if self.compute not in _COMPUTE:
-            raise ValueError(f"[mi355x].extractor_dtype = {self.compute!r}: expected one of {sorted(_COMPUTE)}")
         self.lib.check(self.lib.spr_vgg_plan_create_ex(self.arch, self.block, _COMPUTE[self.compute], C.byref(handle)))
         self.handle = handle
         self.n_convs = self.lib.spr_vgg16_num_convs(handle)

@@ -43,6 +43,13 @@ def test_emu_resnet50_layer1():
     ec.check_resnet50(5, (40, 36), HostDevice(), emu_library(), n_images=1)
 
 
+@pytest.mark.parametrize("compute,hw", [("bfloat16", (40, 36)), ("float16", (34, 47))])
+def test_emu_resnet50_layer1_16bit(compute, hw):
+    """layer1 on the 16-bit GEMM kernel under emulation: 1x1 and 3x3 implicit GEMMs with 128-pixel tiles (ragged last tile),
+    the downsample branch, rounded residual operands, float32 NCHW out."""
+    ec.check_resnet50_16(5, hw, HostDevice(), emu_library(), compute)
+
+
 @pytest.mark.parametrize("model,block,hw,rgb", [("EfficientNetV2_M", 2, (40, 36), False), ("EfficientNetV2_M", 5, (40, 32), False),
                                                 ("EfficientNetV2_S", 3, (34, 32), True), ("EfficientNet_B1", 4, (40, 32), False)])
 def test_emu_efficientnet_v2(model, block, hw, rgb):

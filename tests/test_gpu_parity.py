@@ -502,3 +502,10 @@ def test_vgg_on_the_16bit_matrix_cores(torch_dev, lib, compute, arch, block, hw)
     import extractor_cases as ec
 
     ec.check_block16(block, hw, torch_dev, lib, compute, arch=arch, n_images=1 if hw[0] >= 512 else 2)
+
+
+@pytest.mark.parametrize("compute,block,hw", [("bfloat16", 7, (512, 256)), ("float16", 7, (160, 96)), ("bfloat16", 6, (100, 70))])
+def test_resnet50_on_the_16bit_matrix_cores(torch_dev, lib, compute, block, hw):
+    import extractor_cases as ec
+
+    ec.check_resnet50_16(block, hw, torch_dev, lib, compute)
