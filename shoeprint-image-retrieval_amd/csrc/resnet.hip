@@ -336,8 +336,12 @@ __global__ void __launch_bounds__(kThreads, 3)
 conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int cin, int cout,
                    const uint16_t* __restrict__ wts, const float* __restrict__ bias, const uint16_t* __restrict__ res,
                    int relu, uint16_t* __restrict__ out, float* __restrict__ out32) {
-  __shared__ __attribute__((aligned(16))) uint32_t A[kHM * kHRowDw];
-  __shared__ __attribute__((aligned(16))) uint32_t B[kHN * kHRowDw];
+  // one LDS array: the A and B operand tiles in the main loop, the f32 output tile [128][kHT] in the epilogue
+  constexpr int kHT = 68;  // row stride (floats) of the output tile: 16-byte aligned, rows 4 apart half a bank row apart
+  __shared__ __attribute__((aligned(16))) uint32_t lds16[kHM * kHT];
+  static_assert(kHM * kHT >= (kHM + kHN) * kHRowDw, "the output tile covers the operand tiles");
+  uint32_t* A = lds16;
+  uint32_t* B = lds16 + kHM * kHRowDw;
   constexpr int PAD = KS / 2;
   const int Ho = (H + 2 * PAD - KS) / STRIDE + 1, Wo = (W + 2 * PAD - KS) / STRIDE + 1;
   const long long M = static_cast<long long>(n_img) * Ho * Wo;
@@ -417,28 +421,60 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
           acc[i][j] = KIND == SPR_F16 ? mfma_f16_16x16x32(a[i], b[j], acc[i][j]) : mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
     }
   }
-  // ---- epilogue: lane (q, p) owns pixels m0 + 32 wave + 16 i + 4 q + r, channel cb*64 + 16 j + p
+  // ---- epilogue.  Lane (q, p) owns pixels m0 + 32 wave + 16 i + 4 q + r, channel cb*64 + 16 j + p: scattered 2-byte stores
+  // from there would touch 32-byte pieces of 4 rows per instruction.  The accumulators (+ bias) go through LDS as an f32 tile
+  // instead, and leave in the layout of the destination: NHWC 16-bit rows as 16-byte pieces of 8 channels (the residual
+  // operand is read the same way), NCHW float32 as runs of consecutive pixels of one channel.
+  __syncthreads();  // the last chunk's fragments are consumed: the operand tiles may be overwritten
+  float* T = reinterpret_cast<float*>(lds16);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const float bv = bias[cb * kHN + j * 16 + p];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wave * 32 + i * 16 + 4 * q + r;
-      if (m >= M) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ch = cb * kHN + j * 16 + p;
-        float v = acc[i][j][r] + bias[ch];
-        if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + ch]);
-        if (relu) v = fmaxf(v, 0.0f);
-        if (out32) {
-          const int ox = static_cast<int>(m % Wo), oy = static_cast<int>((m / Wo) % Ho);
-          const size_t img = static_cast<size_t>(m / (static_cast<long long>(Wo) * Ho));
-          out32[((img * cout + ch) * Ho + oy) * static_cast<size_t>(Wo) + ox] = v;
-        } else {
-          out[static_cast<size_t>(m) * cout + ch] = rround16<KIND>(v);
-        }
-      }
+      for (int r = 0; r < 4; ++r) T[(wave * 32 + i * 16 + 4 * q + r) * kHT + j * 16 + p] = acc[i][j][r] + bv;
+  }
+  __syncthreads();
+  if (out32) {
+    // thread = (channel c = tid / 4, quarter of the rows): 32 consecutive pixels of one channel each
+    const int c = tid >> 2, part = tid & 3;
+    const int ch = cb * kHN + c;
+    const size_t plane = static_cast<size_t>(Ho) * Wo;
+    for (int k = 0; k < 32; ++k) {
+      const int row = part * 32 + k;
+      const long long m = m0 + row;
+      if (m >= M) break;
+      float v = T[row * kHT + c];
+      if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + ch]);
+      if (relu) v = fmaxf(v, 0.0f);
+      const size_t img = static_cast<size_t>(m / static_cast<long long>(plane));
+      out32[(img * cout + ch) * plane + static_cast<size_t>(m - static_cast<long long>(img) * plane)] = v;
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = sr + 32 * k;  // (the staging role again: 16-byte piece ss of rows sr + 32 k)
+      const long long m = m0 + row;
+      if (m >= M) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const size_t at = static_cast<size_t>(m) * cout + cb * kHN + ss * 8;
+      if (res) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + at);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rvalue16<KIND>(static_cast<uint16_t>(rv[e >> 1] >> (16 * (e & 1))));
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = relu ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
+        o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+      }
+      *reinterpret_cast<u32x4*>(out + at) = o;
+    }
+  }
 }
 
 // ================================================================ EfficientNetV2 (network.py:163-175) building blocks
