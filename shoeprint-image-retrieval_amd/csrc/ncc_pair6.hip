@@ -36,6 +36,10 @@ namespace {
 #ifndef SPR_ABL
 #define SPR_ABL 0
 #endif
+// -DSPR_X6=n: layout experiments (right results), A/B builds of tools/ubench/x6_builds.sh.
+#ifndef SPR_X6
+#define SPR_X6 1
+#endif
 #ifdef SPR_STAMPS
 constexpr int kStampPoints = 12, kStampChannels = 8, kStampFirst = 8;
 __device__ unsigned long long g_stamps[12 * kStampChannels * kStampPoints];
@@ -89,6 +93,18 @@ struct Six {
   static constexpr int NT = C::NT, WAVES = NT / 64;
   static constexpr int RS = 139;  // image row stride (complex): == 11 (mod 32), so the three lanes of a row group
                                   // and the 10 2/3 groups of a 32-lane LDS phase read 32 different banks
+  // Row-pass exchange (16 rows of 63 lanes through the image rows the wave has just read): value r of lane u lies at
+  // image slot 3 r + a(u), row offset o(u) of the wave's 21 rows.  a = u / 21, o = u % 21 (round 2) serves the reads - three
+  // lanes of a row group read the values of lanes 3 grp + tt - with up to eleven two-way bank conflicts per instruction (the
+  // 21-lane blocks of one exchange row start 11 banks apart, the groups inside a block 3).  This map makes the bank of a
+  // value, 11 a + o, equal to u modulo 32 for every lane but one, which is what the 32-lane halves of ds_read_b64 need to be
+  // conflict-free (the stores stay conflict-free per 16 lanes): {a, o} in image elements from the block's base.
+  static __device__ __forceinline__ int xpos(int u) {
+    if (SPR_X6 == 0) return (u / 21) * RS + u % 21;
+    const int a = u < 21 ? 0 : (u < 32 ? 1 : (u < 43 ? 2 : (u < 53 ? 1 : 2)));
+    const int o = u < 21 ? u : (u < 32 ? u - 11 : (u < 43 ? u - 22 : (u < 53 ? u - 43 : (u == 53 ? 9 : u - 54))));
+    return a * RS + o;
+  }
   static constexpr int XR = 65;   // exchange row: one slot per lane of the wave + 1 (bank skew between rows)
   static constexpr int XROWS = 6; // exchange rows in the wave's own buffer (the column pass puts six more into
                                   // the image columns the wave is about to write)
@@ -401,9 +417,10 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       const float kH = 0.86602540378443860f;
       const cf kl = t3 == 1 ? cmake(-0.5f, kH) : cmake(1.0f, 0.0f);  // output a = y0 + kappa s + lambda (i d)
       const cf hb = t3 == 0 ? cmake(kH, 0.0f) : cmake(-kH, 0.0f);    // output b = m + hb (i d)
-      cf* wx = R + (lane / 21) * RS + wv * C::kRowGroups + (lane % 21);  // (lane 63 writes nothing)
-      const cf* rx = R + (grp_r / 7) * RS + wv * C::kRowGroups + 3 * (grp_r % 7) + 3 * t3 * RS;
-      const cf* rx15 = R + (grp_r / 7) * RS + wv * C::kRowGroups + 3 * (grp_r % 7) + 45 * RS;
+      cf* wx = R + S::xpos(lane < 63 ? lane : 62) + wv * C::kRowGroups;  // (lane 63 writes nothing)
+      const cf* rxt[3];
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) rxt[tt] = R + S::xpos(3 * grp_r + tt) + wv * C::kRowGroups;
       wave_sync();  // every lane of the wave has read its image rows
       if (lane < 63 && SPR_ABL != 3) {
 #pragma unroll
@@ -416,7 +433,7 @@ pair6_kernel(Pair6Args g, const unsigned char* __restrict__ pq, size_t q_item_by
       for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)  // row n1 = t3 + 3 pp; rows 16, 17 do not exist: those lanes re-read row 15
-          yv[pp][tt] = pp < 5 ? rx[9 * pp * RS + tt] : rx15[tt];
+          yv[pp][tt] = pp < 5 ? rxt[tt][(9 * pp + 3 * t3) * RS] : rxt[tt][45 * RS];
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) {
         const cf y0 = yv[pp][0], y1 = yv[pp][1], y2 = yv[pp][2];

@@ -67,12 +67,27 @@ rpack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
 
+__device__ __forceinline__ uint16_t sround_bf16(float v) {
+  union { float f; uint32_t u; } c;
+  c.f = v;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  c.u += 0x7fffu + ((c.u >> 16) & 1u);
+  return static_cast<uint16_t>(c.u >> 16);
+}
+__device__ __forceinline__ uint16_t sround_f16(float v) {
+  union { _Float16 h; uint16_t u; } c;
+  c.h = static_cast<_Float16>(v);
+  return c.u;
+}
+
 // ---------------------------------------------------------------- stem: 7x7 s2 p3, 3 -> 64, pre-processing + ReLU fused
 // grid = (tiles of 8x8 output pixels, images); out NHWC [n][Ho][Wo][64]
 __global__ void __launch_bounds__(kThreads)
 stem_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2, float s0,
             float s1, float s2, const float* __restrict__ wts, const float* __restrict__ bias, float* __restrict__ out,
-            int relu) {
+            int relu, int kind16) {
+  // kind16 != 0 (16-bit plans): the activation is stored rounded to float16 / bfloat16 (rounding is monotonic, so the max
+  // pool behind it may take its maximum over the rounded values)
   constexpr int kT = 8, kP = 2 * kT + 5;  // 21 x 21 input patch
   __shared__ float patch[kP * kP * 3];
   __shared__ float wl[147 * 64];
@@ -118,7 +133,12 @@ stem_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, f
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int oy = oy0 + 2 * part + i / 8, ox = ox0 + i % 8;
-    if (oy < Ho && ox < Wo) out[((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + n] = relu ? fmaxf(acc[i], 0.0f) : acc[i];
+    if (oy < Ho && ox < Wo) {
+      const float v = relu ? fmaxf(acc[i], 0.0f) : acc[i];
+      const size_t at = ((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + n;
+      if (kind16 == 0) out[at] = v;
+      else reinterpret_cast<uint16_t*>(out)[at] = kind16 == SPR_F16 ? sround_f16(v) : sround_bf16(v);
+    }
   }
 }
 
@@ -308,25 +328,35 @@ rpack16_kernel(const float* __restrict__ w, const float* __restrict__ b, float* 
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
 
-// 3x3 / stride 2 / pad 1 max pool of the stem's f32 NHWC output into the 16-bit NHWC tensor layer1 reads
-template <int KIND>
+// 3x3 / stride 2 / pad 1 max pool of the stem's (rounded, post-ReLU: non-negative) 16-bit NHWC output into the 16-bit NHWC
+// tensor layer1 reads: eight channels (16 bytes) per work-item; non-negative float16 / bfloat16 values order like their bit
+// patterns, so the maximum is taken on the 16-bit integers
 __global__ void __launch_bounds__(kThreads)
-maxpool3_16_kernel(const float* __restrict__ in, int H, int W, int C, uint16_t* __restrict__ out, size_t total) {
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+maxpool3_16_kernel(const uint16_t* __restrict__ in, int H, int W, int C, uint16_t* __restrict__ out, size_t total8) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c8 = C / 8;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total8;
        i += static_cast<size_t>(gridDim.x) * kThreads) {
-    const int c = static_cast<int>(i % C);
-    size_t p = i / C;
+    const int c = static_cast<int>(i % c8) * 8;
+    size_t p = i / c8;
     const int ox = static_cast<int>(p % Wo); p /= Wo;
     const int oy = static_cast<int>(p % Ho);
     const size_t img = p / Ho;
-    float m = -3.402823466e38f;
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int dy = -1; dy <= 1; ++dy)
       for (int dx = -1; dx <= 1; ++dx) {
         const int y = 2 * oy + dy, x = 2 * ox + dx;
-        if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, in[((img * H + y) * static_cast<size_t>(W) + x) * C + c]);
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + ((img * H + y) * static_cast<size_t>(W) + x) * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t h = (v[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          m[e] = h > m[e] ? h : m[e];
+        }
       }
-    out[i] = rround16<KIND>(m);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = m[2 * e] | (m[2 * e + 1] << 16);
+    *reinterpret_cast<u32x4*>(out + i * 8) = o;
   }
 }
 
@@ -437,19 +467,22 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
   }
   __syncthreads();
   if (out32) {
-    // thread = (channel c = tid / 4, quarter of the rows): 32 consecutive pixels of one channel each
-    const int c = tid >> 2, part = tid & 3;
-    const int ch = cb * kHN + c;
-    const size_t plane = static_cast<size_t>(Ho) * Wo;
-    for (int k = 0; k < 32; ++k) {
-      const int row = part * 32 + k;
-      const long long m = m0 + row;
-      if (m >= M) break;
-      float v = T[row * kHT + c];
-      if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + ch]);
-      if (relu) v = fmaxf(v, 0.0f);
+    // thread = (pixel row of the tile, half of the channels): for one channel, 128 consecutive work-items store 128
+    // consecutive pixels of its plane
+    const int row = tid & 127, c0 = tid >> 7;
+    const long long m = m0 + row;
+    if (m < M) {
+      const size_t plane = static_cast<size_t>(Ho) * Wo;
       const size_t img = static_cast<size_t>(m / static_cast<long long>(plane));
-      out32[(img * cout + ch) * plane + static_cast<size_t>(m - static_cast<long long>(img) * plane)] = v;
+      const size_t pix = static_cast<size_t>(m - static_cast<long long>(img) * plane);
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) {
+        const int c = 2 * k + c0, ch = cb * kHN + c;
+        float v = T[row * kHT + c];
+        if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + ch]);
+        if (relu) v = fmaxf(v, 0.0f);
+        out32[(img * cout + ch) * plane + pix] = v;
+      }
     }
   } else {
 #pragma unroll
@@ -832,7 +865,7 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
     const unsigned tiles = static_cast<unsigned>(ceil_div(h, 8) * ceil_div(w, 8));
     hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w,
                        in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + c.w_off,
-                       pk + c.b_off, buf[1], 1);
+                       pk + c.b_off, buf[1], 1, f32 ? 0 : plan->compute);
     int rc = check_launch("stem_kernel");
     if (rc != SPR_OK) return rc;
     const int hp = (h + 1) / 2, wp = (w + 1) / 2;
@@ -841,11 +874,10 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
     if (plan->compute == SPR_F32) {
       hipLaunchKernelGGL(maxpool3_kernel, pgrid, dim3(kThreads), 0, s, buf[1], h, w, 64, buf[0], total, 64);
     } else {
-      uint16_t* x16 = b16[0];  // the pooled tensor, rounded: layer1's operand
-      if (plan->compute == SPR_F16)
-        hipLaunchKernelGGL(maxpool3_16_kernel<SPR_F16>, pgrid, dim3(kThreads), 0, s, buf[1], h, w, 64, x16, total);
-      else
-        hipLaunchKernelGGL(maxpool3_16_kernel<SPR_BF16>, pgrid, dim3(kThreads), 0, s, buf[1], h, w, 64, x16, total);
+      // (the stem stored its activation rounded to the 16-bit type; the pooled tensor is layer1's operand)
+      const dim3 pgrid8(static_cast<unsigned>(std::min<size_t>((total / 8 + kThreads - 1) / kThreads, 65535 * 16)));
+      hipLaunchKernelGGL(maxpool3_16_kernel, pgrid8, dim3(kThreads), 0, s, reinterpret_cast<const uint16_t*>(buf[1]), h, w, 64,
+                         b16[0], total / 8);
     }
     rc = check_launch("maxpool3_kernel");
     if (rc != SPR_OK) return rc;
@@ -1338,7 +1370,7 @@ extern "C" int spr_densenet_forward(spr_densenet_plan* plan, const uint8_t* imag
     float* stem_out = (o.flags & 4) ? tmp : cat;
     hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w, in_channels,
                        mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + o.w_off, pk + o.b_off, stem_out,
-                       (o.flags & 2) ? 1 : 0);
+                       (o.flags & 2) ? 1 : 0, 0);
     rc = check_launch("stem_kernel");
     if (rc != SPR_OK) return rc;
     if (o.flags & 4) {
