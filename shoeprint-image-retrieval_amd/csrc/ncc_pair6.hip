@@ -37,8 +37,11 @@ namespace {
 #define SPR_ABL 0
 #endif
 // -DSPR_X6=n: layout experiments (right results), A/B builds of tools/ubench/x6_builds.sh.
+// 1: conflict-free map of the row-pass exchange (Six::xpos).  Measured 3 % SLOWER than the round-2 map (304 k against 294 k
+// pairs/s, kernel only, same box, both orders): three read bases instead of one; the conflicts it removes (~80 LDS cycles per
+// wave and channel) are not what the kernel waits for.  Kept for A/B builds.
 #ifndef SPR_X6
-#define SPR_X6 1
+#define SPR_X6 0
 #endif
 #ifdef SPR_STAMPS
 constexpr int kStampPoints = 12, kStampChannels = 8, kStampFirst = 8;

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "spr_common.h"
@@ -406,31 +407,35 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[4], rb[2];
-  auto request = [&](int ch) {
+  // Operand loads run TWO chunks ahead of the matrix work (two register sets, the chunk loop unrolled by two): a chunk's
+  // matrix work is ~0.1 us against ~2 us of memory latency, and with one chunk in flight every chunk paid that latency in
+  // full (measured: 36 chunks of a layer3 3x3 convolution = 66 us).
+  float4 ra[2][4], rb[2][2];
+  auto request = [&](int ch, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     const int tap = ch / cchunks, cc = ch - tap * cchunks;
     const int dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = ay[k] + dy, x = ax[k] + dx;
-      ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[S][k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (abase[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
-        ra[k] = *reinterpret_cast<const float4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
+        ra[S][k] = *reinterpret_cast<const float4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      rb[k] = *reinterpret_cast<const float4*>(wbase + (static_cast<size_t>(ch) * kHN + 32 * k) * kHK);
+      rb[S][k] = *reinterpret_cast<const float4*>(wbase + (static_cast<size_t>(ch) * kHN + 32 * k) * kHK);
   };
   auto slot = [](int row, int s) { return (s ^ ((row >> 1) & 7)) << 2; };  // dword offset of 16-byte slot s inside row `row`
-  request(0);
-  for (int ch = 0; ch < chunks; ++ch) {
+  auto chunk = [&](int ch, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     __syncthreads();  // the previous chunk's fragments are consumed
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[k];
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[S][k];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[k];
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[S][k];
     __syncthreads();
-    if (ch + 1 < chunks) request(ch + 1);
+    if (ch + 2 < chunks) request(ch + 2, set_c);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 a[2], b[4];
@@ -450,7 +455,17 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
         for (int j = 0; j < 4; ++j)
           acc[i][j] = KIND == SPR_F16 ? mfma_f16_16x16x32(a[i], b[j], acc[i][j]) : mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
     }
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  request(0, Set0{});
+  if (chunks > 1) request(1, Set1{});
+  int ch = 0;
+  for (; ch + 1 < chunks; ch += 2) {
+    chunk(ch, Set0{});
+    chunk(ch + 1, Set1{});
   }
+  if (ch < chunks) chunk(ch, Set0{});
   // ---- epilogue.  Lane (q, p) owns pixels m0 + 32 wave + 16 i + 4 q + r, channel cb*64 + 16 j + p: scattered 2-byte stores
   // from there would touch 32-byte pieces of 4 rows per instruction.  The accumulators (+ bias) go through LDS as an f32 tile
   // instead, and leave in the layout of the destination: NHWC 16-bit rows as 16-byte pieces of 8 channels (the residual
