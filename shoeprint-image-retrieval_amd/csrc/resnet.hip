@@ -22,8 +22,8 @@
 // Arithmetic: 17.13 GFLOP per 512x256 image through layer3; bound: fp32 MFMA 157 TFLOP/s.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
-#include <type_traits>
 #include <vector>
 
 #include "spr_common.h"
@@ -361,19 +361,25 @@ maxpool3_16_kernel(const uint16_t* __restrict__ in, int H, int W, int C, uint16_
   }
 }
 
-// grid = (ceil(M / 128), cout / 64).  in / res / out: NHWC 16-bit with cin / cout channels; out32: float32 NCHW (last layer)
-template <int KS, int STRIDE, int KIND>
-__global__ void __launch_bounds__(kThreads, 3)
+// grid = (ceil(M / 128), cout / BN).  in / res / out: NHWC 16-bit with cin / cout channels; out32: float32 NCHW (last layer).
+// BN = 64: four waves x (32 pixels x 64 channels); BN = 128: 2 x 2 waves x (64 pixels x 64 channels) - twice the matrix
+// work per byte staged (these GEMMs run against the L2 -> CU bandwidth, not against the matrix cores: a 128 x 64 x 64 chunk
+// is 43 flop per staged byte, a 128 x 128 x 64 one 64).
+template <int KS, int STRIDE, int KIND, int BN>
+__global__ void __launch_bounds__(kThreads, BN == 128 ? 2 : 3)
 conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int cin, int cout,
                    const uint16_t* __restrict__ wts, const float* __restrict__ bias, const uint16_t* __restrict__ res,
                    int relu, uint16_t* __restrict__ out, float* __restrict__ out32) {
-  // one LDS array: the A and B operand tiles in the main loop, the f32 output tile [128][kHT] in the epilogue
+  // one LDS array: the A and B operand tiles in the main loop, the f32 output tile [128][kHT] (64 channels at a time) in the
+  // epilogue
   constexpr int kHT = 68;  // row stride (floats) of the output tile: 16-byte aligned, rows 4 apart half a bank row apart
-  __shared__ __attribute__((aligned(16))) uint32_t lds16[kHM * kHT];
-  static_assert(kHM * kHT >= (kHM + kHN) * kHRowDw, "the output tile covers the operand tiles");
+  constexpr int kLdsDw = kHM * kHT > (kHM + BN) * kHRowDw ? kHM * kHT : (kHM + BN) * kHRowDw;
+  __shared__ __attribute__((aligned(16))) uint32_t lds16[kLdsDw];
   uint32_t* A = lds16;
   uint32_t* B = lds16 + kHM * kHRowDw;
   constexpr int PAD = KS / 2;
+  constexpr int MI = BN == 128 ? 4 : 2;  // 16-pixel blocks per wave
+  constexpr int BK = BN / 32;            // 16-byte pieces of the B tile per work-item
   const int Ho = (H + 2 * PAD - KS) / STRIDE + 1, Wo = (W + 2 * PAD - KS) / STRIDE + 1;
   const long long M = static_cast<long long>(n_img) * Ho * Wo;
   const int tid = static_cast<int>(threadIdx.x);
@@ -382,8 +388,10 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
   const int cb = static_cast<int>(blockIdx.y);
   const long long m0 = static_cast<long long>(blockIdx.x) * kHM;
   const int cchunks = cin / kHK, chunks = KS * KS * cchunks;
+  const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32;  // first pixel row / first channel of this wave's part of the tile
+  const int wn = BN == 128 ? (wave & 1) * 64 : 0;
 
-  // staging role: 16-byte slot `ss` of rows sr + 32 k (A: k = 0..3, B: k = 0, 1)
+  // staging role: 16-byte slot `ss` of rows sr + 32 k (A: k = 0..3, B: k = 0 .. BK - 1)
   const int sr = tid >> 3, ss = tid & 7;
   int ay[4], ax[4];
   long long abase[4];  // element offset of pixel (img, 0, 0); negative marks a row beyond M
@@ -399,128 +407,125 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
       ay[k] = ax[k] = 0; abase[k] = -1;
     }
   }
-  const uint16_t* wbase = wts + static_cast<size_t>(cb) * chunks * (kHN * kHK) + sr * kHK + ss * 8;
+  // packed weights: [cout / 64][chunk][n: 64][k: 64]; B tile row r belongs to 64-channel block cb * (BN / 64) + r / 64
+  const uint16_t* wbase = wts + ss * 8;
+  const size_t wblock = static_cast<size_t>(chunks) * (kHN * kHK);
 
-  f32x4 acc[2][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Operand loads run TWO chunks ahead of the matrix work (two register sets, the chunk loop unrolled by two): a chunk's
-  // matrix work is ~0.1 us against ~2 us of memory latency, and with one chunk in flight every chunk paid that latency in
-  // full (measured: 36 chunks of a layer3 3x3 convolution = 66 us).
-  float4 ra[2][4], rb[2][2];
-  auto request = [&](int ch, auto set_c) {
-    constexpr int S = decltype(set_c)::value;
+  float4 ra[4], rb[BK];
+  auto request = [&](int ch) {
     const int tap = ch / cchunks, cc = ch - tap * cchunks;
     const int dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = ay[k] + dy, x = ax[k] + dx;
-      ra[S][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (abase[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
-        ra[S][k] = *reinterpret_cast<const float4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
+        ra[k] = *reinterpret_cast<const float4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      rb[S][k] = *reinterpret_cast<const float4*>(wbase + (static_cast<size_t>(ch) * kHN + 32 * k) * kHK);
+    for (int k = 0; k < BK; ++k) {
+      const int r = sr + 32 * k;
+      rb[k] = *reinterpret_cast<const float4*>(wbase + (static_cast<size_t>(cb) * (BN / 64) + r / 64) * wblock +
+                                               (static_cast<size_t>(ch) * kHN + r % 64) * kHK);
+    }
   };
   auto slot = [](int row, int s) { return (s ^ ((row >> 1) & 7)) << 2; };  // dword offset of 16-byte slot s inside row `row`
-  auto chunk = [&](int ch, auto set_c) {
-    constexpr int S = decltype(set_c)::value;
+  request(0);
+  for (int ch = 0; ch < chunks; ++ch) {
     __syncthreads();  // the previous chunk's fragments are consumed
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[S][k];
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[k];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[S][k];
+    for (int k = 0; k < BK; ++k) *reinterpret_cast<float4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[k];
     __syncthreads();
-    if (ch + 2 < chunks) request(ch + 2, set_c);
+    if (ch + 1 < chunks) request(ch + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 a[2], b[4];
+      u32x4 a[MI], b[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wave * 32 + i * 16 + p;
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm + i * 16 + p;
         a[i] = *reinterpret_cast<const u32x4*>(A + row * kHRowDw + slot(row, ks * 4 + q));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = j * 16 + p;
+        const int row = wn + j * 16 + p;
         b[j] = *reinterpret_cast<const u32x4*>(B + row * kHRowDw + slot(row, ks * 4 + q));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = KIND == SPR_F16 ? mfma_f16_16x16x32(a[i], b[j], acc[i][j]) : mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
     }
-  };
-  using Set0 = std::integral_constant<int, 0>;
-  using Set1 = std::integral_constant<int, 1>;
-  request(0, Set0{});
-  if (chunks > 1) request(1, Set1{});
-  int ch = 0;
-  for (; ch + 1 < chunks; ch += 2) {
-    chunk(ch, Set0{});
-    chunk(ch + 1, Set1{});
   }
-  if (ch < chunks) chunk(ch, Set0{});
-  // ---- epilogue.  Lane (q, p) owns pixels m0 + 32 wave + 16 i + 4 q + r, channel cb*64 + 16 j + p: scattered 2-byte stores
+  // ---- epilogue.  Lane (q, p) owns pixels wm + 16 i + 4 q + r, channels wn + 16 j + p of the tile: scattered 2-byte stores
   // from there would touch 32-byte pieces of 4 rows per instruction.  The accumulators (+ bias) go through LDS as an f32 tile
-  // instead, and leave in the layout of the destination: NHWC 16-bit rows as 16-byte pieces of 8 channels (the residual
-  // operand is read the same way), NCHW float32 as runs of consecutive pixels of one channel.
-  __syncthreads();  // the last chunk's fragments are consumed: the operand tiles may be overwritten
+  // of 64 channels at a time instead, and leave in the layout of the destination: NHWC 16-bit rows as 16-byte pieces of 8
+  // channels (the residual operand is read the same way), NCHW float32 as runs of consecutive pixels of one channel.
   float* T = reinterpret_cast<float*>(lds16);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float bv = bias[cb * kHN + j * 16 + p];
+  for (int h = 0; h < BN / 64; ++h) {
+    __syncthreads();  // the operand tiles (or the previous half of the output tile) are consumed
+    const int cbase = cb * BN + h * 64;  // first channel of this half
+    if (wn == h * 64) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const float bv = bias[cbase + j * 16 + p];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) T[(wave * 32 + i * 16 + 4 * q + r) * kHT + j * 16 + p] = acc[i][j][r] + bv;
-  }
-  __syncthreads();
-  if (out32) {
-    // thread = (pixel row of the tile, half of the channels): for one channel, 128 consecutive work-items store 128
-    // consecutive pixels of its plane
-    const int row = tid & 127, c0 = tid >> 7;
-    const long long m = m0 + row;
-    if (m < M) {
-      const size_t plane = static_cast<size_t>(Ho) * Wo;
-      const size_t img = static_cast<size_t>(m / static_cast<long long>(plane));
-      const size_t pix = static_cast<size_t>(m - static_cast<long long>(img) * plane);
-#pragma unroll 4
-      for (int k = 0; k < 32; ++k) {
-        const int c = 2 * k + c0, ch = cb * kHN + c;
-        float v = T[row * kHT + c];
-        if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + ch]);
-        if (relu) v = fmaxf(v, 0.0f);
-        out32[(img * cout + ch) * plane + pix] = v;
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(wm + i * 16 + 4 * q + r) * kHT + j * 16 + p] = acc[i][j][r] + bv;
       }
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = sr + 32 * k;  // (the staging role again: 16-byte piece ss of rows sr + 32 k)
+    __syncthreads();
+    if (out32) {
+      // thread = (pixel row of the tile, half of the channels): for one channel, 128 consecutive work-items store 128
+      // consecutive pixels of its plane
+      const int row = tid & 127, c0 = tid >> 7;
       const long long m = m0 + row;
-      if (m >= M) continue;
-      const float4 lo = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8 + 4);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const size_t at = static_cast<size_t>(m) * cout + cb * kHN + ss * 8;
-      if (res) {
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + at);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rvalue16<KIND>(static_cast<uint16_t>(rv[e >> 1] >> (16 * (e & 1))));
+      if (m < M) {
+        const size_t plane = static_cast<size_t>(Ho) * Wo;
+        const size_t img = static_cast<size_t>(m / static_cast<long long>(plane));
+        const size_t pix = static_cast<size_t>(m - static_cast<long long>(img) * plane);
+#pragma unroll 4
+        for (int k = 0; k < 32; ++k) {
+          const int c = 2 * k + c0, chn = cbase + c;
+          float v = T[row * kHT + c];
+          if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + chn]);
+          if (relu) v = fmaxf(v, 0.0f);
+          out32[(img * cout + chn) * plane + pix] = v;
+        }
       }
-      u32x4 o;
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a0 = relu ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
-        o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+      for (int k = 0; k < 4; ++k) {
+        const int row = sr + 32 * k;  // (the staging role again: 16-byte piece ss of rows sr + 32 k)
+        const long long m = m0 + row;
+        if (m >= M) continue;
+        const float4 lo = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const size_t at = static_cast<size_t>(m) * cout + cbase + ss * 8;
+        if (res) {
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + at);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rvalue16<KIND>(static_cast<uint16_t>(rv[e >> 1] >> (16 * (e & 1))));
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = relu ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
+          o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+        }
+        *reinterpret_cast<u32x4*>(out + at) = o;
       }
-      *reinterpret_cast<u32x4*>(out + at) = o;
     }
   }
 }
@@ -786,14 +791,17 @@ static int launch_gemm16(int kind, const RConv& c, const uint16_t* in, int64_t n
   const int pad = KS / 2;
   const int ho = (h + 2 * pad - KS) / STRIDE + 1, wo = (w + 2 * pad - KS) / STRIDE + 1;
   const long long m = static_cast<long long>(n) * ho * wo;
-  const dim3 grid(static_cast<unsigned>((m + kHM - 1) / kHM), static_cast<unsigned>(c.cout / kHN));
+  const unsigned mt = static_cast<unsigned>((m + kHM - 1) / kHM);
+  // 128-channel tiles where the grid still gives every CU work (SPR_GEMM16_BN = 64 | 128 forces one; tests and A/B runs)
+  static const int forced = [] { const char* v = std::getenv("SPR_GEMM16_BN"); return v && *v ? std::atoi(v) : 0; }();
+  const bool wide = c.cout % 128 == 0 && (forced ? forced == 128 : static_cast<long long>(mt) * (c.cout / 128) >= 512);
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + c.w_off);
-  if (kind == SPR_F16)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, SPR_F16>), grid, dim3(kThreads), 0, s, in,
-                       static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, SPR_BF16>), grid, dim3(kThreads), 0, s, in,
-                       static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32);
+#define SPR_LAUNCH16(KIND_, BN_)                                                                                              \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, KIND_, BN_>), dim3(mt, static_cast<unsigned>(c.cout / BN_)), \
+                     dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32)
+  if (kind == SPR_F16) { if (wide) SPR_LAUNCH16(SPR_F16, 128); else SPR_LAUNCH16(SPR_F16, 64); }
+  else { if (wide) SPR_LAUNCH16(SPR_BF16, 128); else SPR_LAUNCH16(SPR_BF16, 64); }
+#undef SPR_LAUNCH16
   return check_launch("conv_gemm16_kernel");
 }
 

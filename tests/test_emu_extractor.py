@@ -50,6 +50,19 @@ def test_emu_resnet50_layer1_16bit(compute, hw):
     ec.check_resnet50_16(5, hw, HostDevice(), emu_library(), compute)
 
 
+def test_emu_resnet50_16bit_wide_tiles():
+    """The same with the 128-channel tiles forced (SPR_GEMM16_BN=128; read once per process, hence the child process): the
+    launcher picks them only for grids of 512 workgroups and more, which no emulated shape reaches."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SPR_GEMM16_BN="128")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "resnet50_layer1_16bit and bfloat16"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("model,block,hw,rgb", [("EfficientNetV2_M", 2, (40, 36), False), ("EfficientNetV2_M", 5, (40, 32), False),
                                                 ("EfficientNetV2_S", 3, (34, 32), True), ("EfficientNet_B1", 4, (40, 32), False)])
 def test_emu_efficientnet_v2(model, block, hw, rgb):
