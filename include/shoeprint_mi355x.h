@@ -267,10 +267,10 @@ int spr_lab_to_rgb_u8(const uint8_t* lab, uint8_t* rgb, int64_t n_pixels, const 
  * matrix cores, float32 NCHW out.  role: 0 stem, 1/2/3 a bottleneck's convolutions, 4 downsample. */
 typedef struct spr_resnet_plan spr_resnet_plan;
 int spr_resnet_plan_create(int32_t block, spr_resnet_plan** plan_out);
-/* With a compute type, as spr_vgg_plan_create_ex: SPR_F32 (the f32 matrix cores) or SPR_F16 / SPR_BF16 - every convolution
- * behind the stem on v_mfma_f32_16x16x32 with its (BatchNorm-folded) weights and the activations between layers, the residual
- * operand included, rounded to that type; f32 accumulation, bias, residual sum and ReLU; the stem and the float32 NCHW output
- * are unchanged (BASELINE config 3: "ResNet50 layer3 summed maps, bf16"). */
+/* With a compute type, as spr_vgg_plan_create_ex: SPR_F32 (the f32 matrix cores) or SPR_F16 / SPR_BF16 - every convolution,
+ * the 7x7 stem included (its operand is the normalised image), on v_mfma_f32_16x16x32 with its (BatchNorm-folded) weights and
+ * the activations between layers, the residual operand included, rounded to that type; f32 accumulation, bias, residual sum
+ * and ReLU; the float32 NCHW output is unchanged (BASELINE config 3: "ResNet50 layer3 summed maps, bf16"). */
 int spr_resnet_plan_create_ex(int32_t block, int32_t compute, spr_resnet_plan** plan_out);
 int spr_resnet_plan_compute(const spr_resnet_plan* plan);
 void spr_resnet_plan_destroy(spr_resnet_plan* plan);

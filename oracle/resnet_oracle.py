@@ -55,15 +55,15 @@ def _cbn(x, p, stride, pad, compute=None):
 def get_feature_maps(img: np.ndarray, block: int, parameters, compute: str | None = None) -> np.ndarray:
     """uint8 [H,W] (already CLAHE'd) -> float32 [C,h,w]; parameters[i] = (w, b, gamma, beta, running_mean, running_var)
     of convolution i of conv_specs(block) and its BatchNorm.  ``compute`` = "float16" | "bfloat16": the 16-bit compute type of
-    spr_resnet_plan_create_ex - every convolution behind the stem takes rounded weights and a rounded operand, the residual
-    operand is a rounded stored activation, everything else float32."""
+    spr_resnet_plan_create_ex - every convolution, the stem included (its operand is the normalised image), takes rounded
+    weights and a rounded operand, the residual operand is a rounded stored activation, everything else float32."""
     x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None].repeat(3, 1, 1)
     mean = torch.tensor(MEAN, dtype=torch.float32)[:, None, None]
     std = torch.tensor(STD, dtype=torch.float32)[:, None, None]
     x = ((x - mean) / std)[None]
     specs = conv_specs(block)
     with torch.no_grad():
-        x = F.relu(_cbn(x, parameters[0], 2, 3))
+        x = F.relu(_cbn(x, parameters[0], 2, 3, compute))
         x = F.max_pool2d(x, 3, 2, 1)
         i = 1
         while i < len(specs):

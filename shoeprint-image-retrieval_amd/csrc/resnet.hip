@@ -361,6 +361,144 @@ maxpool3_16_kernel(const uint16_t* __restrict__ in, int H, int W, int C, uint16_
   }
 }
 
+// ---------------------------------------------------------------- the stem on the 16-bit matrix cores (16-bit plans)
+// The plain FMA stem_kernel runs at half of the (unpacked) f32 vector peak and is LDS-bound on broadcast reads: 0.5 ms per 32
+// images, a fifth of a 16-bit forward pass.  Here the 7x7 / stride 2 convolution is a GEMM of 128 output pixels (8 x 16) x 64
+// channels x K = 147 taps-and-planes padded to 160 = five v_mfma_f32_16x16x32 k-steps: the normalised input patch (ToTensor,
+// repeat(3), Normalize; zero outside the image) is rounded to the 16-bit type into LDS, every work-item gathers ten 16-byte
+// pieces (8 consecutive k each) of the im2col tile from it through an offset table, and the operand tiles lie K-major
+// ([16-byte slot][row]) so that the sixteen rows x four k-groups of a fragment read fall into different banks as they are.
+// Weights: [k / 8][n: 64][8] 16-bit, zero for k >= 147 (rstem16_pack_kernel).  Output: NHWC 16-bit, ReLU applied.
+constexpr int kSK = 160, kSSlots = kSK / 8, kSTH = 8, kSTW = 16, kSPH = 2 * kSTH + 5, kSPW = 2 * kSTW + 5;
+
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+rstem16_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ packed, size_t w_off,
+                    size_t b_off) {
+  uint16_t* dst = reinterpret_cast<uint16_t*>(packed + w_off);
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < kSK * 64; i += gridDim.x * kThreads) {
+    const int k = i / 64, n = i % 64;  // k = tap * 3 + c
+    float v = 0.0f;
+    if (k < 147) v = w[(static_cast<size_t>(n) * 3 + k % 3) * 49 + k / 3];  // torch layout [n][c][ky][kx]
+    dst[(static_cast<size_t>(k / 8) * 64 + n) * 8 + k % 8] = rround16<KIND>(v);
+  }
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < 64; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
+}
+
+// grid = (tiles of 8 x 16 output pixels, images)
+template <int KIND>
+__global__ void __launch_bounds__(kThreads, 2)
+stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2, float s0,
+              float s1, float s2, const uint16_t* __restrict__ wts, const float* __restrict__ bias, uint16_t* __restrict__ out,
+              int relu) {
+  constexpr int kHT = 68;
+  constexpr int kPatchElems = kSPH * kSPW * 3;                  // 21 x 37 x 3
+  constexpr int kPatchBytes = (kPatchElems * 2 + 2 + 15) / 16 * 16;  // + one zero element the padded k read
+  constexpr int kABytes = kSSlots * 128 * 16, kBBytes = kSSlots * 64 * 16;
+  static_assert(kABytes >= 128 * kHT * 4, "the f32 output tile fits over the A tile");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kABytes + kBBytes + kPatchBytes + kSK * 2];
+  uint32_t* A = reinterpret_cast<uint32_t*>(lds);
+  uint32_t* B = reinterpret_cast<uint32_t*>(lds + kABytes);
+  uint16_t* patch = reinterpret_cast<uint16_t*>(lds + kABytes + kBBytes);
+  uint16_t* koff = reinterpret_cast<uint16_t*>(lds + kABytes + kBBytes + kPatchBytes);
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int tiles_x = ceil_div(Wo, kSTW);
+  const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
+  const int oy0 = ty * kSTH, ox0 = tx * kSTW;
+  const size_t img = blockIdx.y;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  const float mean[3] = {m0, m1, m2}, istd[3] = {s0, s1, s2};
+  // the weights of this layer (20 KB, L2-resident) and the offset table: k -> element of the patch, relative to the pixel's
+  // window origin; the padded k point at the zero element behind the patch
+  for (int i = tid; i < kBBytes / 16; i += kThreads) reinterpret_cast<float4*>(B)[i] = reinterpret_cast<const float4*>(wts)[i];
+  if (tid < kSK) {
+    const int tap = tid / 3, c = tid % 3, dy = tap / 7, dx = tap % 7;
+    koff[tid] = tid < 147 ? static_cast<uint16_t>((dy * kSPW + dx) * 3 + c) : static_cast<uint16_t>(0xffff);
+  }
+  for (int i = tid; i < kSPH * kSPW; i += kThreads) {
+    const int py = i / kSPW, px = i % kSPW;
+    const int y = 2 * oy0 - 3 + py, x = 2 * ox0 - 3 + px;
+    const bool in = y >= 0 && y < H && x >= 0 && x < W;
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.0f;  // zero padding of the NORMALISED tensor
+      if (in) {
+        const size_t pix = (img * H + y) * static_cast<size_t>(W) + x;
+        const float u = static_cast<float>(in_channels == 1 ? images[pix] : images[pix * 3 + c]);
+        v = (u / 255.0f - mean[c]) * istd[c];
+      }
+      patch[i * 3 + c] = rround16<KIND>(v);
+    }
+  }
+  if (tid == 0) patch[kPatchElems] = 0;
+  __syncthreads();
+  {  // im2col: row = output pixel (8 x 16, row-major), ten 16-byte pieces per work-item
+    const int row = tid & 127, half = tid >> 7;
+    const int base = ((row >> 4) * 2 * kSPW + (row & 15) * 2) * 3;
+#pragma unroll
+    for (int j = 0; j < kSSlots / 2; ++j) {
+      const int sl = half * (kSSlots / 2) + j;
+      const u32x4 ko = *reinterpret_cast<const u32x4*>(koff + 8 * sl);
+      u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned k0 = ko[e] & 0xffffu, k1 = ko[e] >> 16;
+        const unsigned a0 = patch[k0 == 0xffffu ? kPatchElems : base + static_cast<int>(k0)];
+        const unsigned a1 = patch[k1 == 0xffffu ? kPatchElems : base + static_cast<int>(k1)];
+        v[e] = a0 | (a1 << 16);
+      }
+      *reinterpret_cast<u32x4*>(A + (sl * 128 + row) * 4) = v;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < kSK / 32; ++ks) {
+    u32x4 a[2], b[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const u32x4*>(A + ((ks * 4 + q) * 128 + wave * 32 + i * 16 + p) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u32x4*>(B + ((ks * 4 + q) * 64 + j * 16 + p) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = KIND == SPR_F16 ? mfma_f16_16x16x32(a[i], b[j], acc[i][j]) : mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+  }
+  __syncthreads();  // the A tile is consumed: the f32 output tile takes its place
+  float* T = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float bv = bias[j * 16 + p];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(wave * 32 + i * 16 + 4 * q + r) * kHT + j * 16 + p] = acc[i][j][r] + bv;
+  }
+  __syncthreads();
+  const int sr = tid >> 3, ss = tid & 7;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = sr + 32 * k;
+    const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+    if (oy >= Ho || ox >= Wo) continue;
+    const float4 lo = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8 + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = relu ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
+      o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+    }
+    *reinterpret_cast<u32x4*>(out + ((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + ss * 8) = o;
+  }
+}
+
 // grid = (ceil(M / 128), cout / BN).  in / res / out: NHWC 16-bit with cin / cout channels; out32: float32 NCHW (last layer).
 // BN = 64: four waves x (32 pixels x 64 channels); BN = 128: 2 x 2 waves x (64 pixels x 64 channels) - twice the matrix
 // work per byte staged (these GEMMs run against the L2 -> CU bandwidth, not against the matrix cores: a 128 x 64 x 64 chunk
@@ -684,7 +822,7 @@ extern "C" int spr_resnet_plan_create_ex(int32_t block, int32_t compute, spr_res
   auto add = [&](int cin, int cout, int ks, int stride, int relu, int res, int role) {
     RConv c{};
     c.cin = cin; c.cout = cout; c.ks = ks; c.stride = stride; c.relu = relu; c.res = res; c.role = role;
-    // (16-bit plans: two weights per float slot, except the stem, which stays a plain f32 FMA kernel)
+    // (16-bit plans: two weights per float slot; the stem's 160 x 64 padded 16-bit matrix fits its f32 allocation)
     c.w_off = off; off += static_cast<size_t>(cout) * cin * ks * ks / ((compute != SPR_F32 && role != 0) ? 2 : 1);
     c.b_off = off; off += static_cast<size_t>(cout);
     off = (off + 3) / 4 * 4;
@@ -756,7 +894,13 @@ extern "C" int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const
     const RConv& c = plan->convs[i];
     if (!weights[i] || !biases[i]) { set_error("spr_resnet_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    if (i > 0 && plan->compute == SPR_F16)
+    if (i == 0 && plan->compute == SPR_F16)
+      hipLaunchKernelGGL(rstem16_pack_kernel<SPR_F16>, dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), c.w_off, c.b_off);
+    else if (i == 0 && plan->compute == SPR_BF16)
+      hipLaunchKernelGGL(rstem16_pack_kernel<SPR_BF16>, dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
+                         static_cast<float*>(packed), c.w_off, c.b_off);
+    else if (i > 0 && plan->compute == SPR_F16)
       hipLaunchKernelGGL(rpack16_kernel<SPR_F16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
                          static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks);
     else if (i > 0 && plan->compute == SPR_BF16)
@@ -886,9 +1030,21 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
   {
     const RConv& c = plan->convs[0];
     const unsigned tiles = static_cast<unsigned>(ceil_div(h, 8) * ceil_div(w, 8));
-    hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w,
-                       in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + c.w_off,
-                       pk + c.b_off, buf[1], 1, f32 ? 0 : plan->compute);
+    if (f32) {
+      hipLaunchKernelGGL(stem_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, in_h, in_w,
+                         in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], pk + c.w_off,
+                         pk + c.b_off, buf[1], 1, 0);
+    } else {
+      const dim3 sgrid(static_cast<unsigned>(ceil_div(h, kSTH) * ceil_div(w, kSTW)), static_cast<unsigned>(n));
+      const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + c.w_off);
+      uint16_t* o16 = reinterpret_cast<uint16_t*>(buf[1]);
+      if (plan->compute == SPR_F16)
+        hipLaunchKernelGGL(stem16_kernel<SPR_F16>, sgrid, dim3(kThreads), 0, s, images, in_h, in_w, in_channels, mean3[0],
+                           mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, pk + c.b_off, o16, 1);
+      else
+        hipLaunchKernelGGL(stem16_kernel<SPR_BF16>, sgrid, dim3(kThreads), 0, s, images, in_h, in_w, in_channels, mean3[0],
+                           mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, pk + c.b_off, o16, 1);
+    }
     int rc = check_launch("stem_kernel");
     if (rc != SPR_OK) return rc;
     const int hp = (h + 1) / 2, wp = (w + 1) / 2;
