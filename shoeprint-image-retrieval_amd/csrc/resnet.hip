@@ -900,7 +900,12 @@ extern "C" int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const
     else if (i == 0 && plan->compute == SPR_BF16)
       hipLaunchKernelGGL(rstem16_pack_kernel<SPR_BF16>, dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
                          static_cast<float*>(packed), c.w_off, c.b_off);
-    else if (i > 0 && plan->compute == SPR_F16)
+    else if (plan->compute != SPR_F32 && c.ks == 3 && c.stride == 1) {
+      // the 3x3 / stride 1 layers of a 16-bit plan run on vgg_conv.hip's patch kernel: its weight layout
+      const int rc3 = pack_conv16_3x3(plan->compute, weights[i], biases[i], static_cast<float*>(packed), c.w_off, c.b_off, c.cin,
+                                      c.cout, hs);
+      if (rc3 != SPR_OK) return rc3;
+    } else if (i > 0 && plan->compute == SPR_F16)
       hipLaunchKernelGGL(rpack16_kernel<SPR_F16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
                          static_cast<float*>(packed), c.w_off, c.b_off, c.cin, c.cout, c.ks);
     else if (i > 0 && plan->compute == SPR_BF16)
@@ -968,7 +973,8 @@ static int resnet_blocks16(const spr_resnet_plan* plan, int64_t n, int h, int w,
     int rc = launch_gemm16<1, 1>(kind, c1, x, n, h, w, pk, nullptr, t1, nullptr, s);
     if (rc != SPR_OK) return rc;
     rc = c2.stride == 2 ? launch_gemm16<3, 2>(kind, c2, t1, n, h, w, pk, nullptr, t2, nullptr, s)
-                        : launch_gemm16<3, 1>(kind, c2, t1, n, h, w, pk, nullptr, t2, nullptr, s);
+                        : launch_conv16_3x3(kind, t1, n, h, w, c2.cin, c2.cout, reinterpret_cast<const uint16_t*>(pk + c2.w_off),
+                                            pk + c2.b_off, c2.relu, t2, s);
     if (rc != SPR_OK) return rc;
     const uint16_t* resid = x;
     if (down) {

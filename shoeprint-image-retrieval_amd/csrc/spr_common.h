@@ -104,6 +104,12 @@ bool direct_geometry(NccGeom& g);  // fills the direct fields; false if the maps
 size_t prepared_query_item_bytes(const NccGeom& g, int method);
 size_t prepared_gallery_item_bytes(const NccGeom& g, int method);
 
+// 16-bit 3x3 / stride 1 convolution of vgg_conv.hip, shared with the ResNet plans (NHWC 16-bit in / out)
+int pack_conv16_3x3(int kind, const float* w, const float* b, float* packed, size_t w_off, size_t b_off, int cin, int cout,
+                    hipStream_t s);
+int launch_conv16_3x3(int kind, const uint16_t* in, int64_t n, int h, int w, int cin, int cout, const uint16_t* w16,
+                      const float* bias, int relu, uint16_t* out, hipStream_t s);
+
 // Load one feature value of any supported storage type as float.
 __device__ __forceinline__ float load_feature(const void* base, size_t idx, int dtype) {
   if (dtype == SPR_F32) return static_cast<const float*>(base)[idx];

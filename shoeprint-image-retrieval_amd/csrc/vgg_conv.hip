@@ -470,6 +470,35 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
 constexpr size_t kConvLds = sizeof(float) * (kPatch * kPatch * kCS + 9 * kTN * kCS);
 
 }  // namespace
+
+// The 16-bit 3x3 / stride 1 convolution for other plans of the library (the ResNet's bottleneck 3x3 layers: the input patch
+// staged once serves all nine taps, 164 flop per staged byte against 43 of the tap-by-tap GEMM tiles of resnet.hip).
+// in / out: NHWC 16-bit; weights as pack_conv16_3x3 writes them.
+int pack_conv16_3x3(int kind, const float* w, const float* b, float* packed, size_t w_off, size_t b_off, int cin, int cout,
+                    hipStream_t s) {
+  if (kind == SPR_F16)
+    hipLaunchKernelGGL(pack_weights16_kernel<kF16>, dim3(256), dim3(kThreads), 0, s, w, b, packed, w_off, b_off, cin, cout);
+  else
+    hipLaunchKernelGGL(pack_weights16_kernel<kBF16>, dim3(256), dim3(kThreads), 0, s, w, b, packed, w_off, b_off, cin, cout);
+  return check_launch("pack_weights16_kernel");
+}
+int launch_conv16_3x3(int kind, const uint16_t* in, int64_t n, int h, int w, int cin, int cout, const uint16_t* w16,
+                      const float* bias, int relu, uint16_t* out, hipStream_t s) {
+  const dim3 grid(static_cast<unsigned>(ceil_div(h, kTile) * ceil_div(w, kTile)), static_cast<unsigned>(cout / kTN),
+                  static_cast<unsigned>(n));
+  if (kind == SPR_F16) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<kF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kConvLds));
+    hipLaunchKernelGGL(conv16_kernel<kF16>, grid, dim3(kThreads), kConvLds, s, in, h, w, cin, cout, w16, bias, relu, 0, 0,
+                       reinterpret_cast<float*>(out), static_cast<float*>(nullptr));
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<kBF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kConvLds));
+    hipLaunchKernelGGL(conv16_kernel<kBF16>, grid, dim3(kThreads), kConvLds, s, in, h, w, cin, cout, w16, bias, relu, 0, 0,
+                       reinterpret_cast<float*>(out), static_cast<float*>(nullptr));
+  }
+  return check_launch("conv16_kernel");
+}
 }  // namespace spr
 
 struct spr_vgg16_plan {
