@@ -56,7 +56,9 @@ int dtype_code(const at::Tensor& t, const char* name) {
     case at::kFloat: return SPR_F32;
     case at::kHalf: return SPR_F16;
     case at::kBFloat16: return SPR_BF16;
-    default: TORCH_CHECK(false, name, ": feature maps are float32, float16 or bfloat16, got ", t.scalar_type());
+    case at::kUInt16: return SPR_BF16;  // bfloat16 bit patterns (numpy has no bfloat16: the host mirror uploads uint16)
+    default: TORCH_CHECK(false, name, ": feature maps are float32, float16 or bfloat16 (or uint16 bfloat16 bit patterns), got ",
+                         t.scalar_type());
   }
   return -1;
 }

@@ -36,6 +36,7 @@ constexpr int kCS = 16;         // LDS stride (floats) of one patch pixel / one 
 // 1 % faster, 14 KB less LDS per workgroup).
 __host__ __device__ inline int qoff(int row, int quarter) { return ((quarter ^ ((row >> 2) & 3)) << 2); }
 constexpr int kTN = 64;         // output channels per workgroup
+constexpr size_t kConvLdsBytes = sizeof(float) * ((16 + 2) * (16 + 2) * 16 + 9 * 64 * 16);  // = kConvLds below
 constexpr int kCk16 = 32;       // 16-bit matrix cores: input channels per chunk = the K of one v_mfma_f32_16x16x32_{bf16,f16}
 
 // Compute types of a plan (spr_vgg_plan_create_ex): the f32 matrix cores (exact, the reference's arithmetic, network.py:235),
@@ -415,14 +416,20 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
     }
   }
 
-  // ---- epilogue: as conv_mfma_kernel (the C/D map of the two MFMA shapes is the same); 16-bit NHWC stores are rounded
+  // ---- epilogue.  The C/D map is conv_mfma_kernel's: lane (q, p) owns pixels x0 + 4q + jj of rows y0 + 4 wave + i, channel
+  // cb*64 + 16j + p.  A 16-bit NHWC result stored from there would be 64 two-byte stores per lane, each instruction touching
+  // 32-byte pieces of four pixels (measured: as many store as load instructions, waves parked 65 % of their time).  So the
+  // activations (after bias / ReLU / pool, f32) go through LDS, 128 pixels x 64 channels at a time, and leave as 16-byte
+  // pieces of eight channels.  The float32 NCHW result of the last layer and the feature taps keep the direct form.
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  constexpr int kET = 68;  // row stride (floats) of the staging tile
+  float* T = reinterpret_cast<float*>(lds);
+  static_assert(128 * kET * sizeof(float) <= kConvLdsBytes, "the staging tile fits the operand tiles");
+  // channel block j of this lane after bias / ReLU, and its feature tap (float32 NCHW, before any pool)
+  auto activations = [&](int j, float (&v)[4][4]) {
     const int ch = cb * kTN + j * 16 + p;
     const float bv = bias[ch];
-    float v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -439,35 +446,83 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
           if (y < H && x < W) tap[((img * cout + ch) * H + y) * static_cast<size_t>(W) + x] = v[i][jj];
         }
     }
-    if (pool) {
+  };
+  if (nchw) {  // the last layer: float32 NCHW, direct
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
+    for (int j = 0; j < 4; ++j) {
+      const int ch = cb * kTN + j * 16 + p;
+      float v[4][4];
+      activations(j, v);
+      if (pool) {
 #pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2) {
-          const float m = fmaxf(fmaxf(v[2 * i2][2 * j2], v[2 * i2][2 * j2 + 1]),
-                                fmaxf(v[2 * i2 + 1][2 * j2], v[2 * i2 + 1][2 * j2 + 1]));
-          const int y = (y0 + 4 * wave) / 2 + i2, x = (x0 + 4 * q) / 2 + j2;
-          if (y < Ho && x < Wo) {
-            if (nchw) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = m;
-            else out16[((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + ch] = round16<KIND>(m);
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+          for (int j2 = 0; j2 < 2; ++j2) {
+            const float m = fmaxf(fmaxf(v[2 * i2][2 * j2], v[2 * i2][2 * j2 + 1]),
+                                  fmaxf(v[2 * i2 + 1][2 * j2], v[2 * i2 + 1][2 * j2 + 1]));
+            const int y = (y0 + 4 * wave) / 2 + i2, x = (x0 + 4 * q) / 2 + j2;
+            if (y < Ho && x < Wo) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = m;
           }
-        }
-    } else {
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int y = y0 + 4 * wave + i, x = x0 + 4 * q + jj;
-          if (y < Ho && x < Wo) {
-            if (nchw) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = v[i][jj];
-            else out16[((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + ch] = round16<KIND>(v[i][jj]);
+          for (int jj = 0; jj < 4; ++jj) {
+            const int y = y0 + 4 * wave + i, x = x0 + 4 * q + jj;
+            if (y < Ho && x < Wo) out[((img * cout + ch) * Ho + y) * static_cast<size_t>(Wo) + x] = v[i][jj];
           }
+      }
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {  // tile rows 8h .. 8h + 7: the waves 2h and 2h + 1
+    __syncthreads();             // the operand tiles / the previous half are consumed
+    if ((wave >> 1) == h) {
+      const int lw = wave & 1;   // this wave's four (pooled: two) pixel rows inside the half
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4][4];
+        activations(j, v);
+        if (pool) {  // the half holds 4 x 8 pooled pixels
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+              const float m = fmaxf(fmaxf(v[2 * i2][2 * j2], v[2 * i2][2 * j2 + 1]),
+                                    fmaxf(v[2 * i2 + 1][2 * j2], v[2 * i2 + 1][2 * j2 + 1]));
+              T[((2 * lw + i2) * 8 + 2 * q + j2) * kET + j * 16 + p] = m;
+            }
+        } else {     // 8 x 16 pixels
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) T[((4 * lw + i) * 16 + 4 * q + jj) * kET + j * 16 + p] = v[i][jj];
         }
+      }
+    }
+    __syncthreads();
+    // a 16-byte piece (pixel row of T, eight channels) per work-item and pass
+    const int rows = pool ? 32 : 128, tw = pool ? 8 : 16;
+    for (int e = tid; e < rows * 8; e += kThreads) {
+      const int row = e >> 3, piece = e & 7;
+      const int ly = row / tw, lx = row - ly * tw;
+      const int y = (pool ? y0 / 2 + 4 * h : y0 + 8 * h) + ly, x = (pool ? x0 / 2 : x0) + lx;
+      if (y >= Ho || x >= Wo) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(T + row * kET + piece * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(T + row * kET + piece * 8 + 4);
+      u32x4 o;
+      o[0] = static_cast<uint32_t>(round16<KIND>(lo.x)) | (static_cast<uint32_t>(round16<KIND>(lo.y)) << 16);
+      o[1] = static_cast<uint32_t>(round16<KIND>(lo.z)) | (static_cast<uint32_t>(round16<KIND>(lo.w)) << 16);
+      o[2] = static_cast<uint32_t>(round16<KIND>(hi.x)) | (static_cast<uint32_t>(round16<KIND>(hi.y)) << 16);
+      o[3] = static_cast<uint32_t>(round16<KIND>(hi.z)) | (static_cast<uint32_t>(round16<KIND>(hi.w)) << 16);
+      *reinterpret_cast<u32x4*>(out16 + ((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + cb * kTN + piece * 8) = o;
     }
   }
 }
 
 constexpr size_t kConvLds = sizeof(float) * (kPatch * kPatch * kCS + 9 * kTN * kCS);
+static_assert(kConvLds == kConvLdsBytes, "one LDS size");
 
 }  // namespace
 
