@@ -555,21 +555,21 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[4], rb[BK];
+  u32x4 ra[4], rb[BK];  // (native vectors: arrays of HIP's float4 struct stayed in scratch memory and made the prefetch synchronous)
   auto request = [&](int ch) {
     const int tap = ch / cchunks, cc = ch - tap * cchunks;
     const int dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = ay[k] + dy, x = ax[k] + dx;
-      ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[k] = u32x4{0u, 0u, 0u, 0u};
       if (abase[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
-        ra[k] = *reinterpret_cast<const float4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
+        ra[k] = *reinterpret_cast<const u32x4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
     }
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
       const int r = sr + 32 * k;
-      rb[k] = *reinterpret_cast<const float4*>(wbase + (static_cast<size_t>(cb) * (BN / 64) + r / 64) * wblock +
+      rb[k] = *reinterpret_cast<const u32x4*>(wbase + (static_cast<size_t>(cb) * (BN / 64) + r / 64) * wblock +
                                                (static_cast<size_t>(ch) * kHN + r % 64) * kHK);
     }
   };
@@ -578,9 +578,9 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
   for (int ch = 0; ch < chunks; ++ch) {
     __syncthreads();  // the previous chunk's fragments are consumed
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[k];
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(A + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = ra[k];
 #pragma unroll
-    for (int k = 0; k < BK; ++k) *reinterpret_cast<float4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[k];
+    for (int k = 0; k < BK; ++k) *reinterpret_cast<u32x4*>(B + (sr + 32 * k) * kHRowDw + slot(sr + 32 * k, ss)) = rb[k];
     __syncthreads();
     if (ch + 1 < chunks) request(ch + 1);
 #pragma unroll

@@ -360,35 +360,37 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
   const uint16_t* in_img = in + img * static_cast<size_t>(H) * W * cin;
   constexpr int kPatchPieces = kPatch * kPatch * 4, kFilterPieces = 9 * kTN * 4;
   constexpr int kPP = (kPatchPieces + kThreads - 1) / kThreads, kFP = kFilterPieces / kThreads;
-  float4 pre_p[kPP], pre_f[kFP];
+  // (native vector types: as arrays of HIP's float4 struct the nine filter pieces stayed in scratch memory - a store and a
+  // load of 160 bytes per lane and chunk behind every global load, which made the prefetch synchronous)
+  u32x4 pre_p[kPP], pre_f[kFP];
   auto request = [&](int cc) {
 #pragma unroll
     for (int k = 0; k < kPP; ++k) {
       const int i = tid + k * kThreads;
       const int pp = i >> 2, qq = i & 3;
       const int y = y0 - 1 + pp / kPatch, x = x0 - 1 + pp % kPatch;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      u32x4 v = {0u, 0u, 0u, 0u};
       if (i < kPatchPieces && y >= 0 && y < H && x >= 0 && x < W)
-        v = *reinterpret_cast<const float4*>(in_img + (static_cast<size_t>(y) * W + x) * cin + cc * kCk16 + qq * 8);
+        v = *reinterpret_cast<const u32x4*>(in_img + (static_cast<size_t>(y) * W + x) * cin + cc * kCk16 + qq * 8);
       pre_p[k] = v;
     }
     const uint16_t* wsrc = wts + (static_cast<size_t>(cb) * nchunks + cc) * (9 * kTN * kCk16);
 #pragma unroll
     for (int k = 0; k < kFP; ++k) {
       const int i = tid + k * kThreads;
-      pre_f[k] = *reinterpret_cast<const float4*>(wsrc + (i >> 2) * kCk16 + (i & 3) * 8);
+      pre_f[k] = *reinterpret_cast<const u32x4*>(wsrc + (i >> 2) * kCk16 + (i & 3) * 8);
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int k = 0; k < kPP; ++k) {
       const int i = tid + k * kThreads;
-      if (i < kPatchPieces) *reinterpret_cast<float4*>(patch + (i >> 2) * kCS + qoff(i >> 2, i & 3)) = pre_p[k];
+      if (i < kPatchPieces) *reinterpret_cast<u32x4*>(patch + (i >> 2) * kCS + qoff(i >> 2, i & 3)) = pre_p[k];
     }
 #pragma unroll
     for (int k = 0; k < kFP; ++k) {
       const int i = tid + k * kThreads;
-      *reinterpret_cast<float4*>(wl + (i >> 2) * kCS + qoff(i >> 2, i & 3)) = pre_f[k];
+      *reinterpret_cast<u32x4*>(wl + (i >> 2) * kCS + qoff(i >> 2, i & 3)) = pre_f[k];
     }
   };
   request(0);
