@@ -200,11 +200,11 @@ typedef struct spr_vgg16_plan spr_vgg16_plan;
  * convolution's weights and bias by the caller when spr_vgg_conv_info reports it inside the truncation. */
 typedef enum spr_vgg_arch { SPR_VGG16 = 0, SPR_VGG19 = 1, SPR_VGG19_BN = 2 } spr_vgg_arch;
 int spr_vgg_plan_create(int32_t arch, int32_t block, spr_vgg16_plan** plan_out);
-/* As spr_vgg_plan_create with a compute type for the 3x3 convolutions behind the first one: SPR_F32 = the f32 matrix cores
+/* As spr_vgg_plan_create with a compute type for the convolutions: SPR_F32 = the f32 matrix cores
  * (exact, the reference's arithmetic: network.py:235 runs the model in float32), SPR_F16 / SPR_BF16 = 16-bit operands with
  * f32 accumulation on v_mfma_f32_16x16x32_{f16,bf16} (BASELINE configs 3 and 5 ask for reduced precision): the weights and
- * the activations BETWEEN layers are rounded to that type (nearest even), bias / ReLU / pool and the last layer's output stay
- * f32, the first convolution stays a plain f32 kernel.  Every later call on the plan (packed bytes, pack, workspace, forward)
+ * the activations BETWEEN layers (and the normalised image the first convolution reads) are rounded to that type (nearest even),
+ * bias / ReLU / pool and the last layer's output stay f32; a plan that consists of the first convolution alone stays f32.  Every later call on the plan (packed bytes, pack, workspace, forward)
  * follows the plan's type; the float32 NCHW output and the argument lists do not change. */
 int spr_vgg_plan_create_ex(int32_t arch, int32_t block, int32_t compute, spr_vgg16_plan** plan_out);
 int spr_vgg_plan_compute(const spr_vgg16_plan* plan);

@@ -58,8 +58,8 @@ def get_feature_maps(img: np.ndarray, block: int, parameters, arch: str = "VGG16
     BatchNorm2d is part of the truncation, (w, b, gamma, beta, running_mean, running_var).
 
     ``compute`` = "float16" | "bfloat16" restates the 16-bit compute type of spr_vgg_plan_create_ex (BUILD-DEFINED: the
-    reference runs float32, network.py:235): every convolution behind the first takes its input and its (BatchNorm-folded)
-    weights ROUNDED to that type, products and sums in float32 (exact products, so only the order of the f32 additions
+    reference runs float32, network.py:235): every convolution - the first one's input is the normalised image - takes its input
+    and its (BatchNorm-folded) weights ROUNDED to that type, products and sums in float32 (exact products, so only the order of the f32 additions
     differs from the matrix cores), bias / ReLU / pool and the last output unrounded."""
     if img.ndim == 3:  # RGB [H,W,3]: transform_rgb = ToTensor + Normalize (network.py:74-87)
         x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0))
@@ -69,6 +69,7 @@ def get_feature_maps(img: np.ndarray, block: int, parameters, arch: str = "VGG16
     std = torch.tensor(ARCHS[arch][3], dtype=torch.float32)[:, None, None]
     x = ((x - mean) / std)[None]
     k = 0
+    n_convs = len(conv_shapes(block, arch))
     with torch.no_grad():
         for op in feature_ops(block, arch):
             if op[0] == "conv":
@@ -81,7 +82,7 @@ def get_feature_maps(img: np.ndarray, block: int, parameters, arch: str = "VGG16
                     scale = gamma / np.sqrt(var + np.float32(1e-5))
                     w = torch.from_numpy(np.ascontiguousarray(p[0] * scale[:, None, None, None]))
                     b = torch.from_numpy(np.ascontiguousarray((p[1] - mu) * scale + beta))
-                if compute and k > 1:
+                if compute and n_convs > 1:  # (a plan that is its first convolution alone stays float32)
                     x, w = round_to(x, compute), round_to(w, compute)
                 x = F.conv2d(x, w, b, stride=1, padding=1)
             elif op[0] == "bn":

@@ -369,39 +369,49 @@ maxpool3_16_kernel(const uint16_t* __restrict__ in, int H, int W, int C, uint16_
 // pieces (8 consecutive k each) of the im2col tile from it through an offset table, and the operand tiles lie K-major
 // ([16-byte slot][row]) so that the sixteen rows x four k-groups of a fragment read fall into different banks as they are.
 // Weights: [k / 8][n: 64][8] 16-bit, zero for k >= 147 (rstem16_pack_kernel).  Output: NHWC 16-bit, ReLU applied.
-constexpr int kSK = 160, kSSlots = kSK / 8, kSTH = 8, kSTW = 16, kSPH = 2 * kSTH + 5, kSPW = 2 * kSTW + 5;
+// The same kernel with KS = 3, STRIDE = 1 (K = 27 padded to 32: one k-step) is the first convolution of the plain VGGs in their
+// 16-bit plans (vgg_conv.hip calls launch_first16).
+constexpr int kSTH = 8, kSTW = 16;  // output pixels per workgroup
+template <int KS, int STRIDE>
+struct First16 {
+  static constexpr int TAPS = KS * KS, KREAL = TAPS * 3, K = (KREAL + 31) / 32 * 32, SLOTS = K / 8;
+  static constexpr int PH = STRIDE * kSTH + KS - STRIDE, PW = STRIDE * kSTW + KS - STRIDE, PAD = KS / 2;
+};
 
-template <int KIND>
+template <int KIND, int KS>
 __global__ void __launch_bounds__(kThreads)
 rstem16_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ packed, size_t w_off,
                     size_t b_off) {
+  using F = First16<KS, 1>;
   uint16_t* dst = reinterpret_cast<uint16_t*>(packed + w_off);
-  for (int i = blockIdx.x * kThreads + threadIdx.x; i < kSK * 64; i += gridDim.x * kThreads) {
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < F::K * 64; i += gridDim.x * kThreads) {
     const int k = i / 64, n = i % 64;  // k = tap * 3 + c
     float v = 0.0f;
-    if (k < 147) v = w[(static_cast<size_t>(n) * 3 + k % 3) * 49 + k / 3];  // torch layout [n][c][ky][kx]
+    if (k < F::KREAL) v = w[(static_cast<size_t>(n) * 3 + k % 3) * F::TAPS + k / 3];  // torch layout [n][c][ky][kx]
     dst[(static_cast<size_t>(k / 8) * 64 + n) * 8 + k % 8] = rround16<KIND>(v);
   }
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < 64; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
 
 // grid = (tiles of 8 x 16 output pixels, images)
-template <int KIND>
+template <int KIND, int KS, int STRIDE>
 __global__ void __launch_bounds__(kThreads, 2)
 stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, float m0, float m1, float m2, float s0,
               float s1, float s2, const uint16_t* __restrict__ wts, const float* __restrict__ bias, uint16_t* __restrict__ out,
               int relu) {
+  using F = First16<KS, STRIDE>;
+  constexpr int kSK = F::K, kSSlots = F::SLOTS, kSPH = F::PH, kSPW = F::PW;
   constexpr int kHT = 68;
-  constexpr int kPatchElems = kSPH * kSPW * 3;                  // 21 x 37 x 3
+  constexpr int kPatchElems = kSPH * kSPW * 3;                  // stem: 21 x 37 x 3
   constexpr int kPatchBytes = (kPatchElems * 2 + 2 + 15) / 16 * 16;  // + one zero element the padded k read
-  constexpr int kABytes = kSSlots * 128 * 16, kBBytes = kSSlots * 64 * 16;
-  static_assert(kABytes >= 128 * kHT * 4, "the f32 output tile fits over the A tile");
+  constexpr int kABytes = kSSlots * 128 * 16 > 128 * kHT * 4 ? kSSlots * 128 * 16 : 128 * kHT * 4;  // (or the f32 output tile)
+  constexpr int kBBytes = kSSlots * 64 * 16;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kABytes + kBBytes + kPatchBytes + kSK * 2];
   uint32_t* A = reinterpret_cast<uint32_t*>(lds);
   uint32_t* B = reinterpret_cast<uint32_t*>(lds + kABytes);
   uint16_t* patch = reinterpret_cast<uint16_t*>(lds + kABytes + kBBytes);
   uint16_t* koff = reinterpret_cast<uint16_t*>(lds + kABytes + kBBytes + kPatchBytes);
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int Ho = (H + 2 * F::PAD - KS) / STRIDE + 1, Wo = (W + 2 * F::PAD - KS) / STRIDE + 1;
   const int tiles_x = ceil_div(Wo, kSTW);
   const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) % tiles_x;
   const int oy0 = ty * kSTH, ox0 = tx * kSTW;
@@ -413,12 +423,12 @@ stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels,
   // window origin; the padded k point at the zero element behind the patch
   for (int i = tid; i < kBBytes / 16; i += kThreads) reinterpret_cast<float4*>(B)[i] = reinterpret_cast<const float4*>(wts)[i];
   if (tid < kSK) {
-    const int tap = tid / 3, c = tid % 3, dy = tap / 7, dx = tap % 7;
-    koff[tid] = tid < 147 ? static_cast<uint16_t>((dy * kSPW + dx) * 3 + c) : static_cast<uint16_t>(0xffff);
+    const int tap = tid / 3, c = tid % 3, dy = tap / KS, dx = tap % KS;
+    koff[tid] = tid < F::KREAL ? static_cast<uint16_t>((dy * kSPW + dx) * 3 + c) : static_cast<uint16_t>(0xffff);
   }
   for (int i = tid; i < kSPH * kSPW; i += kThreads) {
     const int py = i / kSPW, px = i % kSPW;
-    const int y = 2 * oy0 - 3 + py, x = 2 * ox0 - 3 + px;
+    const int y = STRIDE * oy0 - F::PAD + py, x = STRIDE * ox0 - F::PAD + px;
     const bool in = y >= 0 && y < H && x >= 0 && x < W;
     for (int c = 0; c < 3; ++c) {
       float v = 0.0f;  // zero padding of the NORMALISED tensor
@@ -434,7 +444,7 @@ stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels,
   __syncthreads();
   {  // im2col: row = output pixel (8 x 16, row-major), ten 16-byte pieces per work-item
     const int row = tid & 127, half = tid >> 7;
-    const int base = ((row >> 4) * 2 * kSPW + (row & 15) * 2) * 3;
+    const int base = ((row >> 4) * STRIDE * kSPW + (row & 15) * STRIDE) * 3;
 #pragma unroll
     for (int j = 0; j < kSSlots / 2; ++j) {
       const int sl = half * (kSSlots / 2) + j;
@@ -786,6 +796,26 @@ dnet_out_kernel(const float* __restrict__ in, int HW, int C, int ld, const float
 }
 
 }  // namespace
+
+// First convolution (3x3 / stride 1 / pad 1, 3 -> 64) of a plain VGG in a 16-bit plan, pre-processing fused: see stem16_kernel
+int pack_first16(int kind, const float* w, const float* b, float* packed, size_t w_off, size_t b_off, hipStream_t s) {
+  if (kind == SPR_F16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rstem16_pack_kernel<SPR_F16, 3>), dim3(8), dim3(kThreads), 0, s, w, b, packed, w_off, b_off);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rstem16_pack_kernel<SPR_BF16, 3>), dim3(8), dim3(kThreads), 0, s, w, b, packed, w_off, b_off);
+  return check_launch("rstem16_pack_kernel");
+}
+int launch_first16(int kind, const uint8_t* images, int64_t n, int h, int w, int in_channels, const float* mean3,
+                   const float* inv_std3, const uint16_t* w16, const float* bias, int relu, uint16_t* out, hipStream_t s) {
+  const dim3 grid(static_cast<unsigned>(ceil_div(h, kSTH) * ceil_div(w, kSTW)), static_cast<unsigned>(n));
+  if (kind == SPR_F16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(stem16_kernel<SPR_F16, 3, 1>), grid, dim3(kThreads), 0, s, images, h, w, in_channels,
+                       mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, bias, out, relu);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(stem16_kernel<SPR_BF16, 3, 1>), grid, dim3(kThreads), 0, s, images, h, w, in_channels,
+                       mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, bias, out, relu);
+  return check_launch("stem16_kernel");
+}
 }  // namespace spr
 
 struct spr_resnet_plan {
@@ -895,10 +925,10 @@ extern "C" int spr_resnet_pack_weights(spr_resnet_plan* plan, const float* const
     if (!weights[i] || !biases[i]) { set_error("spr_resnet_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
     hipStream_t hs = static_cast<hipStream_t>(stream);
     if (i == 0 && plan->compute == SPR_F16)
-      hipLaunchKernelGGL(rstem16_pack_kernel<SPR_F16>, dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rstem16_pack_kernel<SPR_F16, 7>), dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
                          static_cast<float*>(packed), c.w_off, c.b_off);
     else if (i == 0 && plan->compute == SPR_BF16)
-      hipLaunchKernelGGL(rstem16_pack_kernel<SPR_BF16>, dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rstem16_pack_kernel<SPR_BF16, 7>), dim3(40), dim3(kThreads), 0, hs, weights[i], biases[i],
                          static_cast<float*>(packed), c.w_off, c.b_off);
     else if (plan->compute != SPR_F32 && c.ks == 3 && c.stride == 1) {
       // the 3x3 / stride 1 layers of a 16-bit plan run on vgg_conv.hip's patch kernel: its weight layout
@@ -941,9 +971,10 @@ static int launch_gemm16(int kind, const RConv& c, const uint16_t* in, int64_t n
   const int ho = (h + 2 * pad - KS) / STRIDE + 1, wo = (w + 2 * pad - KS) / STRIDE + 1;
   const long long m = static_cast<long long>(n) * ho * wo;
   const unsigned mt = static_cast<unsigned>((m + kHM - 1) / kHM);
-  // 128-channel tiles where the grid still gives every CU work (SPR_GEMM16_BN = 64 | 128 forces one; tests and A/B runs)
+  // 128-channel tiles only on request (SPR_GEMM16_BN=128; tests and A/B runs)
   static const int forced = [] { const char* v = std::getenv("SPR_GEMM16_BN"); return v && *v ? std::atoi(v) : 0; }();
-  const bool wide = c.cout % 128 == 0 && (forced ? forced == 128 : static_cast<long long>(mt) * (c.cout / 128) >= 512);
+  // (measured on ResNet50 through layer3, batch 32: 17.9 k images/s with 64-channel tiles throughout, 16.9 k with 128)
+  const bool wide = c.cout % 128 == 0 && forced == 128;
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + c.w_off);
 #define SPR_LAUNCH16(KIND_, BN_)                                                                                              \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, KIND_, BN_>), dim3(mt, static_cast<unsigned>(c.cout / BN_)), \
@@ -1045,10 +1076,10 @@ extern "C" int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, 
       const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + c.w_off);
       uint16_t* o16 = reinterpret_cast<uint16_t*>(buf[1]);
       if (plan->compute == SPR_F16)
-        hipLaunchKernelGGL(stem16_kernel<SPR_F16>, sgrid, dim3(kThreads), 0, s, images, in_h, in_w, in_channels, mean3[0],
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem16_kernel<SPR_F16, 7, 2>), sgrid, dim3(kThreads), 0, s, images, in_h, in_w, in_channels, mean3[0],
                            mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, pk + c.b_off, o16, 1);
       else
-        hipLaunchKernelGGL(stem16_kernel<SPR_BF16>, sgrid, dim3(kThreads), 0, s, images, in_h, in_w, in_channels, mean3[0],
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem16_kernel<SPR_BF16, 7, 2>), sgrid, dim3(kThreads), 0, s, images, in_h, in_w, in_channels, mean3[0],
                            mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, pk + c.b_off, o16, 1);
     }
     int rc = check_launch("stem_kernel");

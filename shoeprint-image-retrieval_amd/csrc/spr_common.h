@@ -110,6 +110,11 @@ int pack_conv16_3x3(int kind, const float* w, const float* b, float* packed, siz
 int launch_conv16_3x3(int kind, const uint16_t* in, int64_t n, int h, int w, int cin, int cout, const uint16_t* w16,
                       const float* bias, int relu, uint16_t* out, hipStream_t s);
 
+// first convolution of a plain VGG in a 16-bit plan (resnet.hip: the stem kernel's 3x3 / stride 1 instance)
+int pack_first16(int kind, const float* w, const float* b, float* packed, size_t w_off, size_t b_off, hipStream_t s);
+int launch_first16(int kind, const uint8_t* images, int64_t n, int h, int w, int in_channels, const float* mean3,
+                   const float* inv_std3, const uint16_t* w16, const float* bias, int relu, uint16_t* out, hipStream_t s);
+
 // Load one feature value of any supported storage type as float.
 __device__ __forceinline__ float load_feature(const void* base, size_t idx, int dtype) {
   if (dtype == SPR_F32) return static_cast<const float*>(base)[idx];

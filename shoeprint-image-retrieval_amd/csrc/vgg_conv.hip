@@ -625,7 +625,7 @@ extern "C" int spr_vgg_plan_create_ex(int32_t arch, int32_t block, int32_t compu
     if (has_bn) ++j;
     s.relu = (j < block && ops[j].kind == 'R') ? 1 : 0;
     s.pool = (s.relu && j + 1 < block && ops[j + 1].kind == 'P') ? 1 : 0;
-    // (16-bit plans: two weights per float slot, except the first convolution, which stays a plain f32 FMA kernel)
+    // (16-bit plans: two weights per float slot; the first convolution's 32 x 64 padded 16-bit matrix fits its f32 slab)
     s.w_off = off; off += static_cast<size_t>(s.cout) * s.cin * 9 / ((compute != SPR_F32 && s.cin != 3) ? 2 : 1);
     s.b_off = off; off += static_cast<size_t>(s.cout);
     off = (off + 3) / 4 * 4;  // keep every slab 16-byte aligned
@@ -695,6 +695,12 @@ extern "C" int spr_vgg16_pack_weights(spr_vgg16_plan* plan, const float* const* 
     const Stage& s = plan->stages[i];
     if (!weights[i] || !biases[i]) { set_error("spr_vgg16_pack_weights: null parameter %zu", i); return SPR_ERR_ARG; }
     hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (i == 0 && plan->compute != SPR_F32 && plan->stages.size() > 1) {
+      // 16-bit plans: the first convolution runs on the matrix cores too (K = 27 padded to 32), unless it is the whole plan
+      const int rc0 = pack_first16(plan->compute, weights[i], biases[i], static_cast<float*>(packed), s.w_off, s.b_off, hs);
+      if (rc0 != SPR_OK) return rc0;
+      continue;
+    }
     if (i > 0 && plan->compute == SPR_F16)
       hipLaunchKernelGGL(pack_weights16_kernel<kF16>, dim3(256), dim3(kThreads), 0, hs, weights[i], biases[i],
                          static_cast<float*>(packed), s.w_off, s.b_off, s.cin, s.cout);
@@ -772,7 +778,12 @@ static int vgg_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, i
     for (int t = 0; t < n_taps; ++t)
       if (tap_convs[t] == static_cast<int>(i)) tap = tap_out[t];
     const unsigned tiles = static_cast<unsigned>(ceil_div(h, kTile) * ceil_div(w, kTile));
-    if (i == 0) {
+    if (i == 0 && plan->compute != SPR_F32 && !last) {
+      const int rc = launch_first16(plan->compute, images, n, h, w, in_channels, mean3, inv_std3,
+                                    reinterpret_cast<const uint16_t*>(pk + st.w_off), pk + st.b_off, st.relu,
+                                    reinterpret_cast<uint16_t*>(dst), s);
+      if (rc != SPR_OK) return rc;
+    } else if (i == 0) {
       hipLaunchKernelGGL(conv_first_kernel, dim3(tiles, static_cast<unsigned>(n)), dim3(kThreads), 0, s, images, h, w,
                          in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2],
                          pk + st.w_off, pk + st.b_off, st.relu, last ? 1 : 0, dst, plan->compute == SPR_F32 ? 0 : plan->compute);
