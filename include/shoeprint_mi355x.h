@@ -67,9 +67,11 @@ enum spr_ncc_method {
                          spr_ncc_plan_create returns SPR_ERR_WORKSPACE if that allocation fails */
   SPR_NCC_DIRECT = 2, /* sliding-window correlation in LDS (any shape that fits LDS) */
   SPR_NCC_FFT_POW2 = 3, /* as SPR_NCC_FFT but restricted to power-of-two grids (A/B and fallback for the 3*2^k grids) */
-  SPR_NCC_MFMA = 4    /* sliding-window correlation as a [queries x taps] x [taps x positions] product on the bf16 matrix
-                         cores: bfloat16 or float16 storage, cropped maps of 28 x 12 on both sides (ResNet50 layer3 / VGG16 conv5_3
-                         of a 512 x 256 image, crop 2); SPR_ERR_UNSUPPORTED for anything else */
+  SPR_NCC_MFMA = 4    /* sliding-window correlation as a [queries x taps] x [taps x positions] product on the bf16 / f16 matrix
+                         cores: bfloat16 or float16 storage, cropped search maps up to 28 x 12 and cropped templates up to
+                         30 x 16 (ResNet50 layer3 / VGG16 conv5_3 / EfficientNet stride-16 maps of a 512 x 256 image and their
+                         scaled / rotated query variants; 28 x 12 on both sides has its own tuned instance);
+                         SPR_ERR_UNSUPPORTED for anything else */
 };
 
 typedef void* spr_stream_t;

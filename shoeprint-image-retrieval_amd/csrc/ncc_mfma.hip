@@ -46,19 +46,30 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int TH_, int TW_>
+// TH x TW: the FRAME of positions = the largest cropped search map of the instance (a smaller map sits in its top-left corner:
+// the other positions carry 1/sigma = 0 and zero pixels, which is what the zero padding of 'same' mode puts there anyway).
+// FH x 16: the template frame, FH even; a cropped template of th x tw taps sits in it so that its centre tap (th/2, tw/2) -
+// the tap 'same' mode lays on the output pixel (similarity.py:55) - lands on (CY, CX) = (FH/2, CXF).  MCfg<28, 12> is the
+// equal-size instance of BASELINE config 3 (template = map = 28 x 12: no spare taps, no spare positions);
+// MCfg<28, 12, 30, 8> takes any template up to 30 x 16 on any map up to 28 x 12 (scaled / rotated query variants,
+// similarity.py:230-284, and ragged sets) for one k-step more.
+template <int TH_, int TW_, int FH_ = TH_, int CXF_ = TW_ / 2>
 struct MCfg {
-  static constexpr int TH = TH_, TW = TW_;  // cropped template = cropped search map
+  static constexpr int TH = TH_, TW = TW_;  // frame of positions (cropped search map)
+  static constexpr int FH = FH_;               // template frame rows
   static constexpr int NPOS = TH * TW;
   static constexpr int NTILE = NPOS / 16;      // tiles of 16 positions (row-major positions)
-  static constexpr int KS = TH / 2;            // k-steps: two template rows of 16 taps (TW padded to 16 with zeros)
+  static constexpr int KS = FH / 2;            // k-steps: two template rows of 16 taps (TW padded to 16 with zeros)
   static constexpr int TP = TW == 12 ? 3 : 2;  // tiles t and t + TP cover the same columns DY rows further down
   static constexpr int DY = 16 * TP / TW;
   static constexpr int NTG = NTILE / TP;
   static constexpr int SMAX = DY * (NTG - 1) + 2 * (KS - 1);
-  static constexpr int PR = 2 * TH - 1;  // rows of the zero-padded map
-  static constexpr int CY = TH / 2, CX = TW / 2;
-  static_assert(NPOS % 16 == 0 && TH % 2 == 0 && NTILE % TP == 0 && DY % 2 == 0 && TW <= 16, "unsupported map size");
+  static constexpr int PR = TH + FH - 1;  // rows of the zero-padded map
+  static constexpr int CY = FH / 2, CX = CXF_;
+  // largest template / map the instance takes
+  static constexpr int kMaxTh = 2 * (FH - CY) < 2 * CY + 1 ? 2 * (FH - CY) : 2 * CY + 1;
+  static constexpr int kMaxTw = 2 * (16 - CX) < 2 * CX + 1 ? 2 * (16 - CX) : 2 * CX + 1;
+  static_assert(NPOS % 16 == 0 && FH % 2 == 0 && NTILE % TP == 0 && DY % 2 == 0 && TW <= 16, "unsupported map size");
   // LDS image of one channel: copy k (0..7) holds P shifted left by k elements, in chunks of 8 elements (16 bytes): chunk
   // (copy k, chunk column jj, row r) at jj * JS + r * RS + k * 16 - the eight copies of a row side by side (128 bytes), JS a
   // multiple of the 256-byte bank row.  ds_read_b128 is served in four groups of sixteen lanes that are NOT contiguous
@@ -77,7 +88,7 @@ struct MCfg {
   static_assert(DY * (NTG - 1) < PERIOD, "a tile group may lag the first one by less than a channel");
   static_assert(kBufBytes % 16 == 0, "buffer alignment");
   // prepared layouts
-  static constexpr int kQMapBytes = TH * 16 * 2;           // per channel: template rows padded to 16 taps (bf16)
+  static constexpr int kQMapBytes = FH * 16 * 2;           // per channel: the template frame, rows of 16 taps (16-bit)
   static constexpr int kGChanBytes = 3 * 4 * NPOS;         // per channel: b, b*S1 (float), hi|lo (one word per pixel)
   // exact form: U[position][channel] (query) and V[position][channel] (gallery) follow, channels padded to 16 (zeros)
   static constexpr int kXQ = 64;                           // queries per block = row length of the correction matrix
@@ -105,6 +116,7 @@ struct MfmaArgs {
   // exact form: x[position][gallery item of this launch][query of the block] = sum_c U V, subtracted from the channel sums
   const float* x;
   int x_items;
+  int ih, iw;  // the real (cropped) search map inside the frame of positions: what spr_ncc_maps writes
 };
 
 __device__ __forceinline__ unsigned bf16_round(float v) {  // round to nearest even, finite inputs
@@ -137,22 +149,27 @@ template <class M, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                  size_t item_bytes) {
+  // Real sizes (cropped): template th x tw inside the FH x 16 frame, search map ih x iw inside the TH x TW frame.
+  const int th = g.th, tw = g.tw, ih = g.ih, iw = g.iw;
+  const int fy = M::CY - th / 2, fx = M::CX - tw / 2;  // frame position of template tap (0, 0)
+  constexpr int kMaxPix = M::FH * 16 > M::NPOS ? M::FH * 16 : M::NPOS;
+  constexpr int kSatElems = (M::FH + 1) * 17 > (M::TH + 1) * (M::TW + 1) ? (M::FH + 1) * 17 : (M::TH + 1) * (M::TW + 1);
   unsigned char* lds = dyn_lds();
   double* red = reinterpret_cast<double*>(lds);
   float* x0 = reinterpret_cast<float*>(lds + 64);
-  double* sat1 = reinterpret_cast<double*>(lds + align_up(64 + sizeof(float) * M::NPOS, 16));
-  double* sat2 = sat1 + (M::TH + 1) * (M::TW + 1);
+  double* sat1 = reinterpret_cast<double*>(lds + align_up(64 + sizeof(float) * kMaxPix, 16));
+  double* sat2 = sat1 + kSatElems;
   const int c = static_cast<int>(blockIdx.x);
   const size_t item = blockIdx.y;
   const int tid = static_cast<int>(threadIdx.x);
   const int cp = pad16(g.channels);
   unsigned char* out_item = prepared + item * item_bytes;
   const uint16_t* raw = static_cast<const uint16_t*>(maps);
-  auto build_tables = [&]() {
-    if (sat_blocked_fits(M::TH, M::TW))
-      build_sat_pair_blocked(x0, M::TH, M::TW, sat1, sat2);
+  auto build_tables = [&](int h, int w) {
+    if (sat_blocked_fits(h, w))
+      build_sat_pair_blocked(x0, h, w, sat1, sat2);
     else
-      build_sat_pair(x0, M::TH, M::TW, sat1, sat2);
+      build_sat_pair(x0, h, w, sat1, sat2);
   };
   // Conditioning.  The raw operands make  num = R - corrections  a difference of numbers (mean / sigma)^2 times larger than
   // num (measured: 4e-4 on scores of maps offset by 100 sigma).  A channel whose values all sit near its mean - the only way
@@ -160,11 +177,11 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
   // x - kappa representable for every pixel (checked here, pixel by pixel).  Then x - kappa enters the matrix cores and
   // mean - kappa the corrections: the same algebra, exact products as before, and the cancellation is gone.  Channels spread
   // over several binades fail the check and stay as they are: their mean / sigma is small.
-  auto exact_shift = [&](size_t base, int raw_w, float mean) {  // returns kappa (0: no exact shift exists)
+  auto exact_shift = [&](size_t base, int raw_w, int h, int w, float mean) {  // returns kappa (0: no exact shift exists)
     const float kappa = from_storage(to_storage(mean, g.dtype), g.dtype);
     double bad = 0.0;
-    for (int i = tid; i < M::NPOS; i += wg_size()) {
-      const int y = i / M::TW, x = i - y * M::TW;
+    for (int i = tid; i < h * w; i += wg_size()) {
+      const int y = i / w, x = i - y * w;
       const float d = from_storage(raw[base + static_cast<size_t>(y + g.crop) * raw_w + (x + g.crop)], g.dtype) - kappa;
       if (from_storage(to_storage(d, g.dtype), g.dtype) != d) bad += 1.0;
     }
@@ -183,15 +200,16 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
   if (is_query) {
     const size_t base = (item * g.channels + c) * static_cast<size_t>(g.q_h) * g.q_w;
     float mean;
-    load_centred(maps, base, g.q_w, g.crop, M::TH, M::TW, g.dtype, x0, red, &mean);
-    const float scale = template_scale(x0, M::NPOS, red);
-    const float kappa = exact_shift(base, g.q_w, mean);
-    // template rows in the storage type (as stored, or shifted by kappa), padded to 16 taps
+    load_centred(maps, base, g.q_w, g.crop, th, tw, g.dtype, x0, red, &mean);
+    const float scale = template_scale(x0, th * tw, red);
+    const float kappa = exact_shift(base, g.q_w, th, tw, mean);
+    // the template frame in the storage type (taps as stored, or shifted by kappa; zero outside the template)
     uint16_t* rows = reinterpret_cast<uint16_t*>(out_item + static_cast<size_t>(c) * M::kQMapBytes);
-    for (int i = tid; i < M::TH * 16; i += wg_size()) {
-      const int u = i >> 4, v = i & 15;
-      rows[i] = v < M::TW ? static_cast<uint16_t>(shifted_bits(base + static_cast<size_t>(u + g.crop) * g.q_w + (v + g.crop), kappa))
-                          : static_cast<uint16_t>(0);
+    for (int i = tid; i < M::FH * 16; i += wg_size()) {
+      const int u = (i >> 4) - fy, v = (i & 15) - fx;
+      rows[i] = (u >= 0 && u < th && v >= 0 && v < tw)
+                    ? static_cast<uint16_t>(shifted_bits(base + static_cast<size_t>(u + g.crop) * g.q_w + (v + g.crop), kappa))
+                    : static_cast<uint16_t>(0);
     }
     float* sc = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kQMapBytes);
     if (tid == 0) {
@@ -200,53 +218,61 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
     }
     if constexpr (EXACT) {
       float* U = sc + 2 * g.channels;
-      build_tables();
-      const int stride = M::TW + 1;
+      build_tables(th, tw);
+      const int stride = tw + 1;
       for (int i = tid; i < M::NPOS; i += wg_size()) {
         const int y = i / M::TW, x = i - y * M::TW;
-        // taps (u, v) whose pixel (y + u - CY, x + v - CX) lies inside the map
-        const int u0 = M::CY - y > 0 ? M::CY - y : 0, u1 = M::CY - y + M::TH < M::TH ? M::CY - y + M::TH : M::TH;
-        const int v0 = M::CX - x > 0 ? M::CX - x : 0, v1 = M::CX - x + M::TW < M::TW ? M::CX - x + M::TW : M::TW;
-        const double st0 = sat1[u1 * stride + v1] - sat1[u0 * stride + v1] - sat1[u1 * stride + v0] + sat1[u0 * stride + v0];
+        // taps (u, v) whose pixel (y + u - th/2, x + v - tw/2) lies inside the map
+        const int u0 = th / 2 - y > 0 ? th / 2 - y : 0, u1 = th / 2 - y + ih < th ? th / 2 - y + ih : th;
+        const int v0 = tw / 2 - x > 0 ? tw / 2 - x : 0, v1 = tw / 2 - x + iw < tw ? tw / 2 - x + iw : tw;
+        double st0 = 0.0;
+        if (y < ih && x < iw && u1 > u0 && v1 > v0)
+          st0 = sat1[u1 * stride + v1] - sat1[u0 * stride + v1] - sat1[u1 * stride + v0] + sat1[u0 * stride + v0];
         store_column(U, i, scale * static_cast<float>(st0));
       }
     }
   } else {
     const size_t base = (item * g.channels + c) * static_cast<size_t>(g.g_h) * g.g_w;
     float mean;
-    load_centred(maps, base, g.g_w, g.crop, M::TH, M::TW, g.dtype, x0, red, &mean);
-    const float kappa = EXACT ? exact_shift(base, g.g_w, mean) : 0.0f;
+    load_centred(maps, base, g.g_w, g.crop, ih, iw, g.dtype, x0, red, &mean);
+    const float kappa = EXACT ? exact_shift(base, g.g_w, ih, iw, mean) : 0.0f;
     if constexpr (EXACT) mean -= kappa;  // from here on: the mean of the map as the matrix cores see it
     float* eb = reinterpret_cast<float*>(out_item + static_cast<size_t>(c) * M::kGChanBytes);
     float* ebs = eb + M::NPOS;
     unsigned* hl = reinterpret_cast<unsigned*>(ebs + M::NPOS);
     for (int i = tid; i < M::NPOS; i += wg_size()) {
+      const int y = i / M::TW, x = i - y * M::TW;
+      const bool inside = y < ih && x < iw;
       if constexpr (EXACT) {
-        const int y = i / M::TW, x = i - y * M::TW;
-        hl[i] = shifted_bits(base + static_cast<size_t>(y + g.crop) * g.g_w + (x + g.crop), kappa) << 16;
+        hl[i] = inside ? shifted_bits(base + static_cast<size_t>(y + g.crop) * g.g_w + (x + g.crop), kappa) << 16 : 0u;
       } else {
-        const float v = x0[i];
+        const float v = inside ? x0[y * iw + x] : 0.0f;
         const unsigned hi = bf16_round(v);
         const unsigned lo = bf16_round(v - bf16_value(hi));
         hl[i] = (hi << 16) | lo;
       }
     }
-    build_tables();
+    build_tables(ih, iw);
     if constexpr (EXACT) {  // the mean of the channel, behind V: vcol_mfma_kernel turns b and the means into V[position][channel]
       float* means = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kGChanBytes) +
                      static_cast<size_t>(M::NPOS) * cp;
       if (tid == 0) means[c] = mean;
     }
-    const double inv_n = 1.0 / static_cast<double>(M::NPOS);
+    const double inv_n = 1.0 / static_cast<double>(th * tw);
     for (int i = tid; i < M::NPOS; i += wg_size()) {
       const int y = i / M::TW, x = i - y * M::TW;
-      const double s1 = window_sum(sat1, M::TH, M::TW, M::TH, M::TW, y, x);
-      const double s2 = window_sum(sat2, M::TH, M::TW, M::TH, M::TW, y, x);
+      if (y >= ih || x >= iw) {  // a position of the frame outside the map: weight 0
+        eb[i] = 0.0f;
+        ebs[i] = 0.0f;
+        continue;
+      }
+      const double s1 = window_sum(sat1, ih, iw, th, tw, y, x);
+      const double s2 = window_sum(sat2, ih, iw, th, tw, y, x);
       const float inv = inv_sigma_from_sums(s1, s2, inv_n);
       eb[i] = inv;
       if constexpr (EXACT) {
-        const int y0 = y - M::CY > 0 ? y - M::CY : 0, y1 = y - M::CY + M::TH < M::TH ? y - M::CY + M::TH : M::TH;
-        const int xa = x - M::CX > 0 ? x - M::CX : 0, xb = x - M::CX + M::TW < M::TW ? x - M::CX + M::TW : M::TW;
+        const int y0 = y - th / 2 > 0 ? y - th / 2 : 0, y1 = y - th / 2 + th < ih ? y - th / 2 + th : ih;
+        const int xa = x - tw / 2 > 0 ? x - tw / 2 : 0, xb = x - tw / 2 + tw < iw ? x - tw / 2 + tw : iw;
         const double si = s1 + static_cast<double>(mean) * static_cast<double>((y1 - y0) * (xb - xa));  // window sum of the raw map
         ebs[i] = inv * static_cast<float>(si);
       } else {
@@ -511,7 +537,8 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
                 const float* V = reinterpret_cast<const float*>(g_item + static_cast<size_t>(g.channels) * M::kGChanBytes);
                 m -= U[static_cast<size_t>(pos) * cp + chan] * V[static_cast<size_t>(pos) * cp + chan];
               }
-              maps_out[static_cast<size_t>(chan) * M::NPOS + 16 * t + col] = m;
+              const int py = (16 * t + col) / M::TW, px = (16 * t + col) - py * M::TW;
+              if (py < g.ih && px < g.iw) maps_out[(static_cast<size_t>(chan) * g.ih + py) * g.iw + px] = m;
             }
           }
         }
@@ -640,10 +667,24 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
   }
 }
 
-using M2812 = MCfg<28, 12>;
+using M2812 = MCfg<28, 12>;          // template = map = 28 x 12 (BASELINE config 3 / conv5_3 of config 5)
+using MGEN = MCfg<28, 12, 30, 8>;    // any template up to 30 x 16 on any map up to 28 x 12
+static_assert(MGEN::kMaxTh == 30 && MGEN::kMaxTw == 16, "general instance");
 
+bool mfma_tuned_shape(const NccGeom& g) {
+  return g.th == M2812::TH && g.tw == M2812::TW && g.ih == M2812::TH && g.iw == M2812::TW;
+}
 bool mfma_shape_ok(const NccGeom& g) {
-  return (g.dtype == SPR_BF16 || g.dtype == SPR_F16) && g.th == M2812::TH && g.tw == M2812::TW && g.ih == M2812::TH && g.iw == M2812::TW;
+  if (g.dtype != SPR_BF16 && g.dtype != SPR_F16) return false;
+  if (mfma_tuned_shape(g)) return true;
+  return g.th >= 1 && g.tw >= 1 && g.ih >= 1 && g.iw >= 1 && g.th <= MGEN::kMaxTh && g.tw <= MGEN::kMaxTw && g.ih <= MGEN::TH &&
+         g.iw <= MGEN::TW;
+}
+
+// the instance of a plan: f(M2812{}) or f(MGEN{})
+template <class F>
+auto with_instance(const NccGeom& g, F&& f) {
+  return g.mfma_general ? f(MGEN{}) : f(M2812{});
 }
 
 }  // namespace
@@ -652,6 +693,7 @@ constexpr int kCorrItems = 1024;  // gallery items per launch of the exact form 
 
 bool mfma_geometry(NccGeom& g) {
   if (!mfma_shape_ok(g)) return false;
+  g.mfma_general = mfma_tuned_shape(g) ? 0 : 1;
   // SPR_NCC_MFMA_EXACT=0: the centred search map as hi + lo (two MFMAs per tile step, no correction matrix)
   const char* e = std::getenv("SPR_NCC_MFMA_EXACT");
   g.mfma_exact = !(e && e[0] == '0') || g.dtype == SPR_F16;  // half-precision maps: the exact form only (both operands raw)
@@ -660,12 +702,16 @@ bool mfma_geometry(NccGeom& g) {
 }
 
 size_t mfma_query_item_bytes(const NccGeom& g) {
-  size_t b = static_cast<size_t>(g.channels) * (M2812::kQMapBytes + 8);
-  if (g.mfma_exact) b += sizeof(float) * M2812::NPOS * static_cast<size_t>(pad16(g.channels));
-  return align_up(b, 256);
+  return with_instance(g, [&](auto m) {
+    using M = decltype(m);
+    size_t b = static_cast<size_t>(g.channels) * (M::kQMapBytes + 8);
+    if (g.mfma_exact) b += sizeof(float) * M::NPOS * static_cast<size_t>(pad16(g.channels));
+    return align_up(b, 256);
+  });
 }
 size_t mfma_gallery_item_bytes(const NccGeom& g) {
-  size_t b = static_cast<size_t>(g.channels) * M2812::kGChanBytes;
+  size_t b = static_cast<size_t>(g.channels) * M2812::kGChanBytes;  // (both instances: the 28 x 12 frame of positions)
+  static_assert(M2812::kGChanBytes == MGEN::kGChanBytes && M2812::NPOS == MGEN::NPOS, "one frame of positions");
   if (g.mfma_exact) b += sizeof(float) * (M2812::NPOS + 1) * static_cast<size_t>(pad16(g.channels));  // V, then the means
   return align_up(b, 256);
 }
@@ -673,10 +719,11 @@ size_t mfma_workspace_bytes(const NccGeom& g) {
   return g.mfma_exact ? sizeof(float) * M2812::NPOS * static_cast<size_t>(kCorrItems) * M2812::kXQ : 0;
 }
 
-int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream) {
-  if (n == 0) return SPR_OK;
-  using M = M2812;
-  const size_t lds = align_up(64 + sizeof(float) * M::NPOS, 16) + 2 * sizeof(double) * (M::TH + 1) * (M::TW + 1);
+template <class M>
+static int launch_prep_mfma_m(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream) {
+  constexpr int kMaxPix = M::FH * 16 > M::NPOS ? M::FH * 16 : M::NPOS;
+  constexpr int kSatElems = (M::FH + 1) * 17 > (M::TH + 1) * (M::TW + 1) ? (M::FH + 1) * 17 : (M::TH + 1) * (M::TW + 1);
+  const size_t lds = align_up(64 + sizeof(float) * kMaxPix, 16) + 2 * sizeof(double) * kSatElems;
   const size_t item_bytes = is_query ? mfma_query_item_bytes(g) : mfma_gallery_item_bytes(g);
   auto kernel = g.mfma_exact ? prep_mfma_kernel<M, true> : prep_mfma_kernel<M, false>;
   // one wave per (item, channel): maps of 336 pixels leave a 256-lane workgroup waiting at its ~20 barriers
@@ -691,10 +738,14 @@ int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t 
   return rc;
 }
 
-template <bool EXACT, bool F16>
+int launch_prep_mfma(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream) {
+  if (n == 0) return SPR_OK;
+  return with_instance(g, [&](auto m) { return launch_prep_mfma_m<decltype(m)>(g, is_query, maps, n, prepared, stream); });
+}
+
+template <class M, bool EXACT, bool F16>
 static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
                               int64_t ld, int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream) {
-  using M = M2812;
   auto kernel = maps_out ? pair_mfma_kernel<M, true, EXACT, F16> : pair_mfma_kernel<M, false, EXACT, F16>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
   const size_t q_item = mfma_query_item_bytes(g), g_item = mfma_gallery_item_bytes(g);
@@ -709,7 +760,7 @@ static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, cons
       const int64_t n = ng - g0 < max_g ? ng - g0 : max_g;
       MfmaArgs a{g.channels, static_cast<int>(nq), static_cast<int>(n), static_cast<long long>(ld),
                  static_cast<long long>(col0 + g0), accumulate, static_cast<unsigned>(q_item), static_cast<unsigned>(g_item),
-                 nullptr, 0};
+                 nullptr, 0, g.ih, g.iw};
       hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n), q_blocks), dim3(kThreads), M::kLdsBytes, stream, a, pqb,
                          pgb + static_cast<size_t>(g0) * g_item, scores, maps_out);
       const int rc = check_launch("pair_mfma_kernel");
@@ -733,7 +784,7 @@ static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, cons
       int rc = check_launch("corr_mfma_kernel");
       if (rc != SPR_OK) return rc;
       MfmaArgs a{g.channels, nq_here, n, static_cast<long long>(ld), static_cast<long long>(col0 + g0), accumulate,
-                 static_cast<unsigned>(q_item), static_cast<unsigned>(g_item), xws, n};
+                 static_cast<unsigned>(q_item), static_cast<unsigned>(g_item), xws, n, g.ih, g.iw};
       hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n), 1), dim3(kThreads), M::kLdsBytes, stream, a,
                          pqb + static_cast<size_t>(q0) * q_item, pgb + static_cast<size_t>(g0) * g_item,
                          scores ? scores + static_cast<size_t>(q0) * ld : nullptr, maps_out);
@@ -747,9 +798,13 @@ static int launch_pair_mfma_t(const NccGeom& g, const void* pq, int64_t nq, cons
 int launch_pair_mfma(const NccGeom& g, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores, int64_t ld,
                      int64_t col0, int accumulate, float* maps_out, float* xws, hipStream_t stream) {
   if (nq == 0 || ng == 0) return SPR_OK;
-  if (g.dtype == SPR_F16) return launch_pair_mfma_t<true, true>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
-  return g.mfma_exact ? launch_pair_mfma_t<true, false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream)
-                      : launch_pair_mfma_t<false, false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
+  return with_instance(g, [&](auto m) {
+    using M = decltype(m);
+    if (g.dtype == SPR_F16)
+      return launch_pair_mfma_t<M, true, true>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
+    return g.mfma_exact ? launch_pair_mfma_t<M, true, false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream)
+                        : launch_pair_mfma_t<M, false, false>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out, xws, stream);
+  });
 }
 
 }  // namespace spr

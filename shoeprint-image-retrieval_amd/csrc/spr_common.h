@@ -57,6 +57,7 @@ struct NccGeom {
   int strips_per_thread;
   // matrix-core method only -----------------------------------------------------------------
   int mfma_exact;      // 1: raw search map on the matrix cores + correction matrix (ncc_mfma.hip), 0: hi + lo
+  int mfma_general;    // 1: the general instance (template up to 30 x 16 on a map up to 28 x 12), 0: the 28 x 12 / 28 x 12 one
 };
 
 constexpr int kStrip = 8;  // output pixels per register strip in the direct kernel

@@ -187,11 +187,52 @@ def check_mfma_method(make_scorer, channels, nq, ng, tol=TIGHT):
     maps = dev.to_host(sc.ncc_maps_device(plan, pq, pg))
     want = np.stack([oracle.normxcorr(qf[0][c, 2:-2, 2:-2], gf[1][c, 2:-2, 2:-2], precise=True) for c in range(channels)])
     np.testing.assert_allclose(maps, want, atol=20 * tol, rtol=0)
-    # other shapes and storage types stay with the other methods; asking for the method outright is refused there
-    assert sc.plan(channels, (30, 16), (32, 16), dtype="bfloat16").method != _lib.NCC_MFMA
+    # larger maps and float32 storage stay with the other methods; asking for the method outright is refused there
+    assert sc.plan(channels, (32, 16), (33, 16), dtype="bfloat16").method != _lib.NCC_MFMA   # map beyond the 28 x 12 frame
+    assert sc.plan(channels, (36, 16), (32, 16), dtype="bfloat16").method != _lib.NCC_MFMA   # template beyond 30 x 16
+    assert sc.plan(channels, (30, 16), (32, 16), dtype="bfloat16").method == _lib.NCC_MFMA   # the general instance
     assert sc.plan(channels, (32, 16), (32, 16), dtype=np.float32).method != _lib.NCC_MFMA
     with pytest.raises(Exception, match="matrix-core"):
         make_scorer("mfma").plan(channels, (32, 16), (32, 16), dtype=np.float32)
+
+
+# (raw query map, raw gallery map) sizes of the GENERAL matrix-core instance (crop 2 per edge: templates up to 30 x 16 on maps
+# up to 28 x 12): the scaled variants of a 32 x 16 query at the reference's run.toml scales (1.04 -> 33 x 16, 1.08 -> 34 x 17;
+# similarity.py:264-278 truncates int(w * s)), a shrunk one, the largest template, an odd-sized template on a smaller map
+# (ragged sets, dataloader.py:231-237), a tiny template, a map narrower than the frame
+MFMA_GENERAL_SHAPES = [((33, 16), (32, 16)), ((34, 17), (32, 16)), ((28, 14), (32, 16)), ((34, 20), (32, 16)),
+                       ((31, 15), (30, 14)), ((7, 6), (32, 16)), ((32, 16), (21, 9))]
+
+
+def check_mfma_general_shapes(make_scorer, channels=5, nq=3, ng=4, tol=TIGHT, shapes=None):
+    """Unequal template / map sizes on the matrix cores (MCfg<28, 12, 30, 8>): "auto" picks the method, scores equal the
+    oracle on the rounded features - both storage types, both forms of the method - and the per-channel maps of one pair."""
+    from shoeprint_image_retrieval_amd import _lib
+
+    for k, (qs, gs) in enumerate(shapes or MFMA_GENERAL_SHAPES):
+        g = [np.maximum(synth.gallery_features(61 + k, i, channels, *gs), 0) for i in range(ng)]
+        q = [np.maximum(synth.gallery_features(67 + k, 10 + i, channels, *qs), 0) for i in range(nq)]
+        q[1][channels - 1] = 0.0  # a dead query channel
+        g[ng - 1][0] = 0.0        # a dead gallery channel
+        qb, gb = synth.bfloat16_bits(np.stack(q)), synth.bfloat16_bits(np.stack(g))
+        qf, gf = list(synth.from_bfloat16_bits(qb)), list(synth.from_bfloat16_bits(gb))
+        ref = oracle.similarity_matrix(qf, gf, precise=True)
+        sc = make_scorer("auto")
+        dev = sc.dev
+        plan = sc.plan(channels, qs, gs, dtype="bfloat16")
+        assert plan.method == _lib.NCC_MFMA, (qs, gs)
+        got = dev.to_host(sc.scores_device(dev.to_device(qb), dev.to_device(gb)))
+        np.testing.assert_allclose(got, ref, atol=tol, rtol=0, err_msg=f"bfloat16 {qs} on {gs}")
+        pq = sc.prepare_queries(plan, dev.to_device(qb[:1]))
+        pg = sc.prepare_gallery(plan, dev.to_device(gb[1:2]))
+        maps = dev.to_host(sc.ncc_maps_device(plan, pq, pg))
+        want = np.stack([oracle.normxcorr(qf[0][c, 2:-2, 2:-2], gf[1][c, 2:-2, 2:-2], precise=True) for c in range(channels)])
+        assert maps.shape == want.shape
+        np.testing.assert_allclose(maps, want, atol=20 * tol, rtol=0, err_msg=f"maps {qs} on {gs}")
+        q16, g16 = np.stack(q).astype(np.float16), np.stack(g).astype(np.float16)
+        ref16 = oracle.similarity_matrix(list(q16.astype(np.float32)), list(g16.astype(np.float32)), precise=True)
+        got16 = dev.to_host(sc.scores_device(dev.to_device(q16), dev.to_device(g16)))
+        np.testing.assert_allclose(got16, ref16, atol=tol, rtol=0, err_msg=f"float16 {qs} on {gs}")
 
 
 def check_mfma_method_fp16(make_scorer, channels, nq, ng, tol=TIGHT):

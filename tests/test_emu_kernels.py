@@ -185,6 +185,17 @@ def test_emu_matrix_core_method_fp16():
     pc.check_mfma_method_fp16(emu_scorer, 3, 18, 2)
 
 
+def test_emu_matrix_core_general_shapes():
+    """The general instance of the matrix-core scorer (templates up to 30 x 16 on maps up to 28 x 12) under emulation."""
+    pc.check_mfma_general_shapes(emu_scorer, channels=3, nq=2, ng=3)
+
+
+def test_emu_matrix_core_general_shapes_split_form(monkeypatch):
+    monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")
+    pc.check_mfma_general_shapes(emu_scorer, channels=2, nq=2, ng=2, shapes=pc.MFMA_GENERAL_SHAPES[:3],
+                                 )
+
+
 @pytest.mark.parametrize("exact", ["1", "0"])
 def test_emu_matrix_core_method_conditioning(monkeypatch, exact):
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", exact)

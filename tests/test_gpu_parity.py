@@ -101,6 +101,46 @@ def test_matrix_core_method_conditioning(lib, monkeypatch, exact):
     pc.check_mfma_degenerate_channels(_make_scorer(lib))
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
+def test_matrix_core_general_shapes(lib, monkeypatch, exact, capsys):
+    """Templates up to 30 x 16 on maps up to 28 x 12 (the scaled / rotated query variants of 32 x 16 maps at the reference's
+    run.toml scales, ragged sets) on the matrix cores at EfficientNetV2_M's block-6 width (176 channels), both forms; and the
+    rate of one such plan against the FFT form it replaces, printed."""
+    import time
+
+    monkeypatch.setenv("SPR_NCC_MFMA_EXACT", exact)
+    pc.check_mfma_general_shapes(_make_scorer(lib), channels=176, nq=5, ng=6)
+    if exact == "0":
+        return
+    import torch
+    from shoeprint_image_retrieval_amd import synth
+
+    nq, ng, c = 64, 2048, 176
+    rates = {}
+    for method in ("auto", "fft"):
+        sc = _make_scorer(lib)(method)
+        dev = sc.dev
+        g = dev.zeros((ng, c, 32, 16), np.float32)
+        lib.check(lib.spr_synth_gallery(dev.ptr(g), 0, ng, c, 32, 16, 5, dev.stream()))
+        q = dev.zeros((nq, c, 33, 16), np.float32)   # a query batch scaled by 1.04 (similarity.py:264-278)
+        lib.check(lib.spr_synth_gallery(dev.ptr(q), 5000, nq, c, 33, 16, 5, dev.stream()))
+        q, g = q.to(torch.bfloat16), g.to(torch.bfloat16)
+        plan = sc.plan(c, (33, 16), (32, 16), dtype="bfloat16")
+        pq, pg = sc.prepare_queries(plan, q), sc.prepare_gallery(plan, g)
+        out = dev.zeros((nq, ng), np.float32)
+        sc.score_prepared(plan, pq, nq, pg, ng, out, ng, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sc.score_prepared(plan, pq, nq, pg, ng, out, ng, 0)
+        torch.cuda.synchronize()
+        rates[method] = (3 * nq * ng / (time.perf_counter() - t0), dev.to_host(out))
+    np.testing.assert_allclose(rates["auto"][1], rates["fft"][1], atol=pc.TIGHT, rtol=0)
+    with capsys.disabled():
+        print(f"\n[33x16 on 32x16 bf16, 176 ch] matrix cores {rates['auto'][0] / 1e6:.2f} M pairs/s, FFT form {rates['fft'][0] / 1e6:.2f} M pairs/s")
+    assert rates["auto"][0] > rates["fft"][0]
+
+
 def test_matrix_core_method_split_form(lib, monkeypatch):
     monkeypatch.setenv("SPR_NCC_MFMA_EXACT", "0")
     pc.check_mfma_method(_make_scorer(lib), 256, 70, 3)
