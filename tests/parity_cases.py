@@ -199,9 +199,10 @@ def check_mfma_method(make_scorer, channels, nq, ng, tol=TIGHT):
 # (raw query map, raw gallery map) sizes of the GENERAL matrix-core instance (crop 2 per edge: templates up to 30 x 16 on maps
 # up to 28 x 12): the scaled variants of a 32 x 16 query at the reference's run.toml scales (1.04 -> 33 x 16, 1.08 -> 34 x 17;
 # similarity.py:264-278 truncates int(w * s)), a shrunk one, the largest template, an odd-sized template on a smaller map
-# (ragged sets, dataloader.py:231-237), a tiny template, a map narrower than the frame
+# (ragged sets, dataloader.py:231-237), a small template (8 x 5 taps; windows of a handful of post-ReLU pixels are often
+# constant, and their variance is rounding noise in the reference itself), a map narrower than the frame
 MFMA_GENERAL_SHAPES = [((33, 16), (32, 16)), ((34, 17), (32, 16)), ((28, 14), (32, 16)), ((34, 20), (32, 16)),
-                       ((31, 15), (30, 14)), ((7, 6), (32, 16)), ((32, 16), (21, 9))]
+                       ((31, 15), (30, 14)), ((12, 9), (32, 16)), ((32, 16), (21, 9))]
 
 
 def check_mfma_general_shapes(make_scorer, channels=5, nq=3, ng=4, tol=TIGHT, shapes=None):
