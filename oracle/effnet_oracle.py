@@ -89,6 +89,10 @@ def arch_ops(model_str: str, block: int) -> list[dict]:
                             block_end=0, names=(f"{pre}.{k}.fc1", f"{pre}.{k}.fc2")))
             k += 1
             conv(exp, cout, 1, 1, 0, res, 1)
+    if block >= len(st) + 2:  # the whole of `features`: the closing 1x1 convolution + BatchNorm + SiLU
+        cin, f = st[-1][5], len(st) + 1
+        ops.append(dict(kind=0, cin=cin, cout=1280 if model_str in _V2 else 4 * cin, ks=1, stride=1, act=2, res=0, sq=0, feature=f,
+                        block_end=1, names=(f"features.{f}.0", f"features.{f}.1")))
     return ops
 
 

@@ -1210,9 +1210,9 @@ extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_pl
     set_error("spr_effnet_plan_create: arch %d (0 .. 2 = EfficientNetV2_S / _M / _L, 3 .. 8 = EfficientNet_B1 / B2 / B3 / B4 / B5 / B7)", arch);
     return SPR_ERR_ARG;
   }
-  if (block < 1 || block > n_stages + 1) {
-    set_error("spr_effnet_plan_create: block %d: features[:block] with block in [1, %d] (the last 1x1 convolution is not built)",
-              block, n_stages + 1);
+  if (block < 1 || block > n_stages + 2) {
+    set_error("spr_effnet_plan_create: block %d: features[:block] with block in [1, %d] (= len(model.features))", block,
+              n_stages + 2);
     return SPR_ERR_ARG;
   }
   spr_effnet_plan* plan = new (std::nothrow) spr_effnet_plan();
@@ -1230,7 +1230,7 @@ extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_pl
   };
   const int stem_out = stages[0].cin;
   conv(3, stem_out, 3, 2, 2, 0, 0, 1, 0, 16);
-  for (int st = 0; st < block - 1; ++st) {
+  for (int st = 0; st < block - 1 && st < n_stages; ++st) {
     const EStage& g = stages[st];
     for (int l = 0; l < g.layers; ++l) {
       const int cin = l == 0 ? g.cin : g.cout, stride = l == 0 ? g.stride : 1;
@@ -1261,6 +1261,12 @@ extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_pl
         conv(exp, g.cout, 1, 1, 0, res, 1, 1, st + 1, pad64(exp));
       }
     }
+  }
+  if (block == n_stages + 2) {
+    // the closing 1x1 convolution + BatchNorm + SiLU of `features`: 1280 channels in the V2 models, four times the last stage's
+    // width in the B-series (torchvision: last_channel or 4 * lastconv_input_channels)
+    const int cin = stages[n_stages - 1].cout;
+    conv(cin, arch <= 2 ? 1280 : 4 * cin, 1, 1, 2, 0, 0, 1, n_stages + 1, pad64(cin));
   }
   plan->packed_floats = off;
   *plan_out = plan;

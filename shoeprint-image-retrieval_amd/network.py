@@ -66,10 +66,16 @@ def effnet_state_names(ops) -> list[tuple[str, str]]:
     features.s = stage s, .l = block l of the stage, .block.k = its k-th sub-module - and not checked against a checkpoint:
     none is available offline."""
     names, layer, slot = [], {}, 0
-    for op in ops:
+    for i, op in enumerate(ops):
         f = op["feature"]
         if f == 0:
             names.append(("features.0.0", "features.0.1"))
+            continue
+        # the closing 1x1 convolution of `features` is a Conv2dNormActivation of its own, like the stem: a feature that
+        # consists of one plain 1x1 convolution with SiLU (inside a stage a 1x1 + SiLU is an expansion, never a block's end)
+        if (op["kind"] == 0 and op["ks"] == 1 and op["act"] == 2 and op["block_end"] and i == len(ops) - 1
+                and (i == 0 or ops[i - 1]["feature"] != f)):
+            names.append((f"features.{f}.0", f"features.{f}.1"))
             continue
         pre = f"features.{f}.{layer.setdefault(f, 0)}.block.{slot}"
         names.append((f"{pre}.fc1", f"{pre}.fc2") if op["kind"] == 2 else (f"{pre}.0", f"{pre}.1"))
@@ -78,6 +84,29 @@ def effnet_state_names(ops) -> list[tuple[str, str]]:
             layer[f] += 1
             slot = 0
     return names
+
+
+def effnet_plan_ops(lib, handle) -> list[dict]:
+    """The op list of an spr_effnet_plan (see Model.effnet_ops)."""
+    keys = ("kind", "cin", "cout", "cin_p", "cout_p", "ks", "stride", "act", "res", "sq", "feature", "w_off", "b_off",
+            "w2_off", "b2_off", "block_end")
+    out = []
+    for i in range(lib.spr_effnet_num_ops(handle)):
+        info = (C.c_int32 * 16)()
+        lib.check(lib.spr_effnet_op_info(handle, i, info))
+        out.append(dict(zip(keys, list(info))))
+    return out
+
+
+def densenet_plan_ops(lib, handle) -> list[dict]:
+    """The op list of an spr_densenet_plan (see Model.densenet_ops)."""
+    keys = ("kind", "cin", "cout", "c_off", "ctot", "flags", "feature", "w_off", "b_off", "s_off", "t_off")
+    out = []
+    for i in range(lib.spr_densenet_num_ops(handle)):
+        info = (C.c_int32 * 12)()
+        lib.check(lib.spr_densenet_op_info(handle, i, info))
+        out.append(dict(zip(keys, list(info))))
+    return out
 
 
 def densenet_state_names(ops) -> list[tuple]:
@@ -184,14 +213,7 @@ class Model:
         """The flattened layers of features[:block]: kind (0 convolution, 1 depthwise 3x3, 2 squeeze-excitation), real and
         padded widths, kernel size, stride, activation, residual flag, hidden width, index into ``features`` and the offsets
         (floats) of the layer's parameters in the packed buffer."""
-        keys = ("kind", "cin", "cout", "cin_p", "cout_p", "ks", "stride", "act", "res", "sq", "feature", "w_off", "b_off",
-                "w2_off", "b2_off", "block_end")
-        out = []
-        for i in range(self.n_convs):
-            info = (C.c_int32 * 16)()
-            self.lib.check(self.lib.spr_effnet_op_info(self.handle, i, info))
-            out.append(dict(zip(keys, list(info))))
-        return out
+        return effnet_plan_ops(self.lib, self.handle)
 
     def _load_effnet_parameters(self, config):
         global _warned
@@ -266,13 +288,7 @@ class Model:
     def densenet_ops(self) -> list[dict]:
         """The layers of features[:block]: kind (0 stem, 1 dense 1x1, 2 dense 3x3, 3 transition, 4 closing BatchNorm), widths,
         channel offset / width of the block tensor, stem flags, index into ``features`` and packed offsets (floats)."""
-        keys = ("kind", "cin", "cout", "c_off", "ctot", "flags", "feature", "w_off", "b_off", "s_off", "t_off")
-        out = []
-        for i in range(self.n_convs):
-            info = (C.c_int32 * 12)()
-            self.lib.check(self.lib.spr_densenet_op_info(self.handle, i, info))
-            out.append(dict(zip(keys, list(info))))
-        return out
+        return densenet_plan_ops(self.lib, self.handle)
 
     def _load_densenet_parameters(self, config):
         global _warned

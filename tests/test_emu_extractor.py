@@ -86,22 +86,28 @@ def test_architecture_tables_against_the_oracles_own():
     from oracle import densenet_oracle, effnet_oracle
     from shoeprint_image_retrieval_amd import network
 
-    lib, dev = emu_library(), HostDevice()
-    for model_str in network._EFFNET_MODELS:
+    import ctypes
+
+    lib = emu_library()  # (plans only: no parameters are generated, nothing is launched)
+    for model_str, (arch, *_rest) in network._EFFNET_MODELS.items():
         n_stages = len(effnet_oracle.stages(model_str))
-        for block in range(1, n_stages + 2):
-            m = network.Model({"model": {"type": model_str}}, block, device=dev, library=lib)
-            ec.check_effnet_tables(model_str, block, m.effnet_ops())
-            m.close()
+        for block in range(1, n_stages + 3):  # up to the whole of `features`, the closing 1x1 convolution included
+            handle = ctypes.c_void_p()
+            lib.check(lib.spr_effnet_plan_create(arch, block, ctypes.byref(handle)))
+            ec.check_effnet_tables(model_str, block, network.effnet_plan_ops(lib, handle))
+            lib.spr_effnet_plan_destroy(handle)
     for block in range(1, 13):
-        m = network.Model({"model": {"type": "DenseNet_201"}}, block, device=dev, library=lib)
-        ec.check_densenet_tables(block, m.densenet_ops())
-        m.close()
+        handle = ctypes.c_void_p()
+        lib.check(lib.spr_densenet_plan_create(block, ctypes.byref(handle)))
+        ec.check_densenet_tables(block, network.densenet_plan_ops(lib, handle))
+        lib.spr_densenet_plan_destroy(handle)
     # pinned by hand
     out = lambda model, block: [o for o in effnet_oracle.arch_ops(model, block) if o["kind"] == 0][-1]["cout"]
     assert out("EfficientNetV2_M", 6) == 176 and out("EfficientNetV2_S", 7) == 256 and out("EfficientNetV2_L", 8) == 640
     assert out("EfficientNet_B7", 1) == 64 and out("EfficientNet_B1", 1) == 32 and out("EfficientNet_B4", 1) == 48
     assert out("EfficientNet_B7", 8) == 640 and out("EfficientNet_B3", 8) == 384 and out("EfficientNet_B5", 8) == 512
+    assert out("EfficientNetV2_M", 9) == 1280 and out("EfficientNetV2_S", 8) == 1280 and out("EfficientNet_B7", 9) == 2560
+    assert out("EfficientNet_B2", 9) == 1408 and effnet_oracle.arch_ops("EfficientNetV2_S", 8)[-1]["names"] == ("features.7.0", "features.7.1")
     depth = lambda model: [s[6] for s in effnet_oracle.stages(model)]
     assert depth("EfficientNet_B7") == [4, 7, 7, 10, 10, 13, 4] and depth("EfficientNet_B1") == [2, 3, 3, 4, 4, 5, 2]
     assert depth("EfficientNet_B4") == [2, 4, 4, 6, 6, 8, 2] and depth("EfficientNetV2_M") == [3, 5, 5, 7, 14, 18, 5]

@@ -7,7 +7,7 @@ TAG=$1
 O=$R/gpurun_out/${TAG}_prof
 rm -rf $O; mkdir -p $O
 cd /tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-extractor"
+B="python3 $R/bench.py --no-cpu-baseline --no-extractor --no-secondary"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o x -- $B > $O/stats.log 2>&1 || { echo stats failed; tail -3 $O/stats.log; exit 1; }
 echo "stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o x -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1 || { echo fetch failed; exit 1; }
