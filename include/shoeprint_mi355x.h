@@ -292,7 +292,8 @@ int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, int64_t n, 
 /* ------------------------------------------------------------------ EfficientNetV2 feature extractor
  * network.py:163-175 (model choice), :185-186 (`list(model.features.children())[:block]`), :60-71 / :74-87 (transforms).
  * arch: 0 = EfficientNetV2_S, 1 = EfficientNetV2_M (the reference's run.toml default), 2 = EfficientNetV2_L, 3 .. 8 =
- * EfficientNet_B1, B2, B3, B4, B5, B7 (network.py:139-162); block in [1, stages + 1]: the stem and block - 1 stages of torchvision's efficientnet_v2 (the closing 1x1 convolution is not built).
+ * EfficientNet_B1, B2, B3, B4, B5, B7 (network.py:139-162); block in [1, stages + 2] = [1, len(model.features)]: the stem, block - 1
+ * stages and, with the last value, the closing 1x1 convolution of torchvision's efficientnet / efficientnet_v2.
  * The plan flattens the graph into layers (spr_effnet_op_info: int32[16] = kind {0 convolution, 1 depthwise 3x3, 2 squeeze-
  * excitation}, cin, cout, cin_p, cout_p, ksize, stride, act {0 none, 2 SiLU}, res, sq, feature index, offsets in floats of
  * w, b, w2, b2 in the packed buffer, block_end).  The caller folds eval-mode BatchNorm (eps 1e-3) into the convolutions and writes
@@ -303,6 +304,15 @@ int spr_resnet_forward(spr_resnet_plan* plan, const uint8_t* images, int64_t n, 
  * images / mean3 / inv_std3 / out as for spr_vgg16_forward (out: device float32 [n, C, h, w], real channels only). */
 typedef struct spr_effnet_plan spr_effnet_plan;
 int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_plan** plan_out);
+/* With a compute type (as spr_vgg_plan_create_ex): SPR_F16 / SPR_BF16 run every convolution on v_mfma_f32_16x16x32 with the
+ * activations between layers stored in that type (the stem reads the rounded normalised image; squeeze-excitation means,
+ * factors and the depthwise weights stay f32).  The caller then packs, at the same offsets:
+ *   stem             w as 16-bit [k / 8][64][8], k = tap * 3 + plane (zero for k >= 27 and for padded channels), b f32 [64]
+ *   convolution      w as 16-bit [cout_p/64][K/64][64][64] with K = tap * cin_p + c, b f32 [cout_p]
+ *   depthwise / squeeze-excitation   as in the f32 plans
+ * A plan that is the stem alone (block 1) must be f32. */
+int spr_effnet_plan_create_ex(int32_t arch, int32_t block, int32_t compute, spr_effnet_plan** plan_out);
+int spr_effnet_plan_compute(const spr_effnet_plan* plan);
 void spr_effnet_plan_destroy(spr_effnet_plan* plan);
 int spr_effnet_num_ops(const spr_effnet_plan* plan);
 int spr_effnet_op_info(const spr_effnet_plan* plan, int32_t i, int32_t* info16);

@@ -99,10 +99,22 @@ def arch_ops(model_str: str, block: int) -> list[dict]:
 ARCH_KEYS = ("kind", "cin", "cout", "ks", "stride", "act", "res", "sq", "feature", "block_end")
 
 
-def get_feature_maps(img: np.ndarray, ops, parameters, mean, std, bn_eps: float = BN_EPS) -> np.ndarray:
+def _round(x: torch.Tensor, compute) -> torch.Tensor:
+    if not compute:
+        return x
+    return x.to({"float16": torch.float16, "bfloat16": torch.bfloat16}[compute]).to(torch.float32)
+
+
+def get_feature_maps(img: np.ndarray, ops, parameters, mean, std, bn_eps: float = BN_EPS, compute: str | None = None) -> np.ndarray:
     """uint8 [H,W] or RGB [H,W,3] (already CLAHE'd) -> float32 [C,h,w].  ``ops``: the layer list of Model.effnet_ops (kind,
     widths, kernel, stride, activation, residual flag, block_end); ``parameters[i]``: (w, b, gamma, beta, running mean,
-    running variance) or, for a squeeze-excitation, (fc1 w, fc1 b, fc2 w, fc2 b)."""
+    running variance) or, for a squeeze-excitation, (fc1 w, fc1 b, fc2 w, fc2 b).
+
+    ``compute`` = "float16" | "bfloat16" restates the 16-bit plans of spr_effnet_plan_create_ex (BUILD-DEFINED): every tensor
+    between layers is stored rounded to that type (the stem reads the rounded normalised image); a convolution takes its
+    BatchNorm-folded weights rounded and, where a squeeze-excitation scales its input, the rounded product x * factor; sums,
+    bias, SiLU, the residual sum, the squeeze-excitation mean / factors and the depthwise weights are float32; the last
+    layer's output is not rounded."""
     if img.ndim == 3:
         x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0))
     else:
@@ -111,6 +123,8 @@ def get_feature_maps(img: np.ndarray, ops, parameters, mean, std, bn_eps: float 
     s = torch.tensor(std, dtype=torch.float32)[:, None, None]
     x = ((x - m) / s)[None]
     block_in, scale = x, None
+    if compute:
+        return _forward16(x, ops, parameters, bn_eps, compute)
     with torch.no_grad():
         for op, p in zip(ops, parameters):
             t = [torch.from_numpy(np.asarray(a, dtype=np.float32)) for a in p]
@@ -130,6 +144,40 @@ def get_feature_maps(img: np.ndarray, ops, parameters, mean, std, bn_eps: float 
             if op["kind"] == 0 and op["res"]:
                 y = y + block_in
             x = y
+            if op["block_end"]:
+                block_in = x
+    return x.numpy().squeeze(0)
+
+
+def _forward16(x, ops, parameters, bn_eps, compute):
+    x = _round(x, compute)  # the stored tensor: what the next layer reads
+    block_in, scale = x, None
+    with torch.no_grad():
+        for i, (op, p) in enumerate(zip(ops, parameters)):
+            last = i + 1 == len(ops)
+            t = [np.asarray(a, dtype=np.float32) for a in p]
+            if op["kind"] == 2:
+                z = x.mean(dim=(2, 3), keepdim=True)
+                z = F.silu(F.conv2d(z, torch.from_numpy(t[0].reshape(op["sq"], op["cin"], 1, 1)), torch.from_numpy(t[1])))
+                scale = torch.sigmoid(F.conv2d(z, torch.from_numpy(t[2].reshape(op["cin"], op["sq"], 1, 1)), torch.from_numpy(t[3])))
+                continue
+            w, b, gamma, beta, mu, var = t
+            s = gamma / np.sqrt(var + np.float32(bn_eps))  # eval-mode BatchNorm folded as the library folds it (float32)
+            wf = torch.from_numpy(np.ascontiguousarray(w * s[:, None, None, None]))
+            bf = torch.from_numpy(np.ascontiguousarray((b - mu) * s + beta))
+            a = x
+            if op["kind"] == 0:
+                if scale is not None:
+                    a = _round(a * scale, compute)
+                    scale = None
+                wf = _round(wf, compute)
+            groups = op["cin"] if op["kind"] == 1 else 1
+            y = F.conv2d(a, wf, bf, stride=op["stride"], padding=op["ks"] // 2, groups=groups)
+            if op["act"] == 2:
+                y = F.silu(y)
+            if op["kind"] == 0 and op["res"]:
+                y = y + block_in
+            x = y if last else _round(y, compute)
             if op["block_end"]:
                 block_in = x
     return x.numpy().squeeze(0)

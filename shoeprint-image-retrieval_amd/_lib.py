@@ -89,6 +89,8 @@ SIGNATURES = {
     "spr_densenet_forward": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        _VP, _VP, _VP, _VP]),
     "spr_effnet_plan_create": (C.c_int, [_I32, _I32, C.POINTER(_VP)]),
+    "spr_effnet_plan_create_ex": (C.c_int, [_I32, _I32, _I32, C.POINTER(_VP)]),
+    "spr_effnet_plan_compute": (C.c_int, [_VP]),
     "spr_effnet_plan_destroy": (None, [_VP]),
     "spr_effnet_num_ops": (C.c_int, [_VP]),
     "spr_effnet_op_info": (C.c_int, [_VP, _I32, C.POINTER(_I32)]),

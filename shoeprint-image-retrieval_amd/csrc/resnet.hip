@@ -502,7 +502,9 @@ stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels,
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float a0 = relu ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
+      // relu: activation code (0 none, 1 ReLU, 2 SiLU)
+      const float a0 = relu == 1 ? fmaxf(v[2 * e], 0.0f) : relu == 2 ? v[2 * e] / (1.0f + expf(-v[2 * e])) : v[2 * e];
+      const float a1 = relu == 1 ? fmaxf(v[2 * e + 1], 0.0f) : relu == 2 ? v[2 * e + 1] / (1.0f + expf(-v[2 * e + 1])) : v[2 * e + 1];
       o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
     }
     *reinterpret_cast<u32x4*>(out + ((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + ss * 8) = o;
@@ -517,7 +519,11 @@ template <int KS, int STRIDE, int KIND, int BN>
 __global__ void __launch_bounds__(kThreads, BN == 128 ? 2 : 3)
 conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int cin, int cout,
                    const uint16_t* __restrict__ wts, const float* __restrict__ bias, const uint16_t* __restrict__ res,
-                   int relu, uint16_t* __restrict__ out, float* __restrict__ out32) {
+                   int relu, uint16_t* __restrict__ out, float* __restrict__ out32, const float* __restrict__ in_scale,
+                   int cout_real) {
+  // relu: activation code (0 none, 1 ReLU behind the residual sum: ResNet bottlenecks, 2 SiLU in FRONT of it: EfficientNet
+  // blocks); in_scale: [image][cin] f32 factors on the input (squeeze-excitation), applied while the operand is staged and
+  // rounded again, or null; cout_real: channels of a float32 NCHW result when cout is padded (0: all of them)
   // one LDS array: the A and B operand tiles in the main loop, the f32 output tile [128][kHT] (64 channels at a time) in the
   // epilogue
   constexpr int kHT = 68;  // row stride (floats) of the output tile: 16-byte aligned, rows 4 apart half a bank row apart
@@ -541,7 +547,7 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
 
   // staging role: 16-byte slot `ss` of rows sr + 32 k (A: k = 0..3, B: k = 0 .. BK - 1)
   const int sr = tid >> 3, ss = tid & 7;
-  int ay[4], ax[4];
+  int ay[4], ax[4], aimg[4];
   long long abase[4];  // element offset of pixel (img, 0, 0); negative marks a row beyond M
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -551,8 +557,9 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
       const long long pimg = pm / (static_cast<long long>(Wo) * Ho);
       ay[k] = py * STRIDE - PAD; ax[k] = px * STRIDE - PAD;
       abase[k] = pimg * H * static_cast<long long>(W) * cin;
+      aimg[k] = static_cast<int>(pimg);
     } else {
-      ay[k] = ax[k] = 0; abase[k] = -1;
+      ay[k] = ax[k] = 0; abase[k] = -1; aimg[k] = 0;
     }
   }
   // packed weights: [cout / 64][chunk][n: 64][k: 64]; B tile row r belongs to 64-channel block cb * (BN / 64) + r / 64
@@ -573,8 +580,22 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
     for (int k = 0; k < 4; ++k) {
       const int y = ay[k] + dy, x = ax[k] + dx;
       ra[k] = u32x4{0u, 0u, 0u, 0u};
-      if (abase[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
+      if (abase[k] >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
         ra[k] = *reinterpret_cast<const u32x4*>(in + abase[k] + (static_cast<long long>(y) * W + x) * cin + cc * kHK + ss * 8);
+        if (in_scale) {  // x * factor, rounded to the operand type again
+          const float* sc = in_scale + static_cast<size_t>(aimg[k]) * cin + cc * kHK + ss * 8;
+          const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+          const float f[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          u32x4 r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = rvalue16<KIND>(static_cast<uint16_t>(ra[k][e] & 0xffffu)) * f[2 * e];
+            const float hi = rvalue16<KIND>(static_cast<uint16_t>(ra[k][e] >> 16)) * f[2 * e + 1];
+            r[e] = static_cast<uint32_t>(rround16<KIND>(lo)) | (static_cast<uint32_t>(rround16<KIND>(hi)) << 16);
+          }
+          ra[k] = r;
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
@@ -642,13 +663,16 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
         const size_t plane = static_cast<size_t>(Ho) * Wo;
         const size_t img = static_cast<size_t>(m / static_cast<long long>(plane));
         const size_t pix = static_cast<size_t>(m - static_cast<long long>(img) * plane);
+        const int creal = cout_real ? cout_real : cout;
 #pragma unroll 4
         for (int k = 0; k < 32; ++k) {
           const int c = 2 * k + c0, chn = cbase + c;
+          if (chn >= creal) continue;
           float v = T[row * kHT + c];
+          if (relu == 2) v = v / (1.0f + expf(-v));
           if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + chn]);
-          if (relu) v = fmaxf(v, 0.0f);
-          out32[(img * cout + chn) * plane + pix] = v;
+          if (relu == 1) v = fmaxf(v, 0.0f);
+          out32[(img * creal + chn) * plane + pix] = v;
         }
       }
     } else {
@@ -661,6 +685,10 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
         const float4 hi = *reinterpret_cast<const float4*>(T + row * kHT + ss * 8 + 4);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const size_t at = static_cast<size_t>(m) * cout + cbase + ss * 8;
+        if (relu == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+        }
         if (res) {
           const u32x4 rv = *reinterpret_cast<const u32x4*>(res + at);
 #pragma unroll
@@ -669,7 +697,7 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float a0 = relu ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
+          const float a0 = relu == 1 ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu == 1 ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
           o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
         }
         *reinterpret_cast<u32x4*>(out + at) = o;
@@ -760,6 +788,64 @@ enet_fc_kernel(const float* __restrict__ pooled, int C, int sq, const float* __r
     for (int j = 0; j < sq; ++j) s = fmaf(w2[static_cast<size_t>(c) * sq + j], hid[j], s);
     scale[img * C + c] = 1.0f / (1.0f + expf(-s));
   }
+}
+
+// ---- 16-bit plans (spr_effnet_plan_create_ex): activations NHWC float16 / bfloat16, the same padding to 64 channels
+// depthwise ks x ks + bias + SiLU: eight channels (16 bytes) of one output pixel per work-item; weights / bias f32 as above
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+enet_dw16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int C, int stride, int ks,
+                 const float* __restrict__ wts, const float* __restrict__ bias, uint16_t* __restrict__ out) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, pad = ks / 2;
+  const int c8 = C / 8;
+  const size_t total = static_cast<size_t>(n_img) * Ho * Wo * c8;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % c8) * 8;
+    size_t p = i / c8;
+    const int ox = static_cast<int>(p % Wo); p /= Wo;
+    const int oy = static_cast<int>(p % Ho);
+    const size_t img = p / Ho;
+    float acc[8];
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+      acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    }
+    for (int dy = 0; dy < ks; ++dy)
+      for (int dx = 0; dx < ks; ++dx) {
+        const int y = oy * stride + dy - pad, x = ox * stride + dx - pad;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + ((img * H + y) * static_cast<size_t>(W) + x) * C + c);
+        const float* wp = wts + static_cast<size_t>(dy * ks + dx) * C + c;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          acc[e] = fmaf(rvalue16<KIND>(static_cast<uint16_t>(v[e >> 1] >> (16 * (e & 1)))), wv[e], acc[e]);
+      }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = acc[2 * e] / (1.0f + expf(-acc[2 * e])), a1 = acc[2 * e + 1] / (1.0f + expf(-acc[2 * e + 1]));
+      o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+    }
+    *reinterpret_cast<u32x4*>(out + i * 8) = o;
+  }
+}
+
+// squeeze-excitation, step 1 on a 16-bit tensor: f32 mean over the pixels.  grid = (C / 64, images)
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+enet_pool16_kernel(const uint16_t* __restrict__ in, int HW, int C, float* __restrict__ pooled) {
+  __shared__ float part[4][64];
+  const int tid = static_cast<int>(threadIdx.x), c = tid & 63, r = tid >> 6;
+  const size_t img = blockIdx.y;
+  const uint16_t* base = in + img * static_cast<size_t>(HW) * C + static_cast<size_t>(blockIdx.x) * 64 + c;
+  float s = 0.0f;
+  for (int p = r; p < HW; p += 4) s += rvalue16<KIND>(base[static_cast<size_t>(p) * C]);
+  part[r][c] = s;
+  __syncthreads();
+  if (r == 0) pooled[img * C + blockIdx.x * 64 + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / static_cast<float>(HW);
 }
 
 // ================================================================ DenseNet building blocks (network.py:176-179)
@@ -964,6 +1050,24 @@ extern "C" size_t spr_resnet_workspace_bytes(const spr_resnet_plan* plan, int64_
   return 4 * align_up(stem * sizeof(float), 256);
 }
 
+// (cin, cout: the channel counts of the tensors = the padded widths of an EfficientNet layer)
+template <int KS, int STRIDE>
+static int launch_gemm16_raw(int kind, int cin, int cout, int act, const uint16_t* w16, const float* bias, const uint16_t* in,
+                             int64_t n, int h, int w, const uint16_t* res, uint16_t* out, float* out32, const float* in_scale,
+                             int cout_real, hipStream_t s) {
+  const int pad = KS / 2;
+  const int ho = (h + 2 * pad - KS) / STRIDE + 1, wo = (w + 2 * pad - KS) / STRIDE + 1;
+  const long long m = static_cast<long long>(n) * ho * wo;
+  const dim3 grid(static_cast<unsigned>((m + kHM - 1) / kHM), static_cast<unsigned>(cout / 64));
+  if (kind == SPR_F16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, SPR_F16, 64>), grid, dim3(kThreads), 0, s, in,
+                       static_cast<int>(n), h, w, cin, cout, w16, bias, res, act, out, out32, in_scale, cout_real);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, SPR_BF16, 64>), grid, dim3(kThreads), 0, s, in,
+                       static_cast<int>(n), h, w, cin, cout, w16, bias, res, act, out, out32, in_scale, cout_real);
+  return check_launch("conv_gemm16_kernel");
+}
+
 template <int KS, int STRIDE>
 static int launch_gemm16(int kind, const RConv& c, const uint16_t* in, int64_t n, int h, int w, const float* pk,
                          const uint16_t* res, uint16_t* out, float* out32, hipStream_t s) {
@@ -978,7 +1082,8 @@ static int launch_gemm16(int kind, const RConv& c, const uint16_t* in, int64_t n
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + c.w_off);
 #define SPR_LAUNCH16(KIND_, BN_)                                                                                              \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_gemm16_kernel<KS, STRIDE, KIND_, BN_>), dim3(mt, static_cast<unsigned>(c.cout / BN_)), \
-                     dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32)
+                     dim3(kThreads), 0, s, in, static_cast<int>(n), h, w, c.cin, c.cout, w16, pk + c.b_off, res, c.relu, out, out32, \
+                     static_cast<const float*>(nullptr), 0)
   if (kind == SPR_F16) { if (wide) SPR_LAUNCH16(SPR_F16, 128); else SPR_LAUNCH16(SPR_F16, 64); }
   else { if (wide) SPR_LAUNCH16(SPR_BF16, 128); else SPR_LAUNCH16(SPR_BF16, 64); }
 #undef SPR_LAUNCH16
@@ -1185,14 +1290,25 @@ inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
 struct spr_effnet_plan {
   int arch, block;
+  int compute;  // SPR_F32 | SPR_F16 | SPR_BF16
   std::vector<EOp> ops;
   size_t packed_floats;
   int max_expand_p;  // widest expanded tensor (squeeze-excitation scratch)
 };
 
 extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_plan** plan_out) {
+  return spr_effnet_plan_create_ex(arch, block, SPR_F32, plan_out);
+}
+
+extern "C" int spr_effnet_plan_compute(const spr_effnet_plan* plan) { return plan ? plan->compute : SPR_ERR_ARG; }
+
+extern "C" int spr_effnet_plan_create_ex(int32_t arch, int32_t block, int32_t compute, spr_effnet_plan** plan_out) {
   if (!plan_out) { set_error("spr_effnet_plan_create: null pointer"); return SPR_ERR_ARG; }
   *plan_out = nullptr;
+  if (compute != SPR_F32 && compute != SPR_F16 && compute != SPR_BF16) {
+    set_error("spr_effnet_plan_create_ex: compute type %d (SPR_F32 | SPR_F16 | SPR_BF16)", compute);
+    return SPR_ERR_ARG;
+  }
   EStage scaled[7];
   const EStage* stages = arch == 0 ? kV2S : arch == 1 ? kV2M : arch == 2 ? kV2L : nullptr;
   const int n_stages = arch == 0 ? 6 : 7;
@@ -1217,7 +1333,7 @@ extern "C" int spr_effnet_plan_create(int32_t arch, int32_t block, spr_effnet_pl
   }
   spr_effnet_plan* plan = new (std::nothrow) spr_effnet_plan();
   if (!plan) { set_error("out of host memory"); return SPR_ERR_ARG; }
-  plan->arch = arch; plan->block = block; plan->max_expand_p = 64;
+  plan->arch = arch; plan->block = block; plan->max_expand_p = 64; plan->compute = compute;
   size_t off = 0;
   auto take = [&](size_t n) { const size_t o = off; off += (n + 3) / 4 * 4; return o; };
   auto conv = [&](int cin, int cout, int ks, int stride, int act, int res, int scaled, int end, int feature, int cin_p) {
@@ -1340,6 +1456,101 @@ static int launch_egemm(const EOp& o, const float* in, int64_t n, int h, int w, 
   return check_launch("conv_gemm_kernel");
 }
 
+// The 16-bit plans' forward pass: the same walk over the flattened layers with float16 / bfloat16 activations (padded to 64
+// channels, the same four buffers: the f32 sizes are kept, half of each is used), the stem on stem16_kernel's 3x3 / stride 2
+// instance, every other convolution on conv_gemm16_kernel (SiLU in front of the residual sum, squeeze-excitation factors on
+// the operand), depthwise convolutions and the squeeze-excitation mean on their 16-bit kernels; float32 NCHW out.
+static int effnet_forward16(const spr_effnet_plan* plan, const uint8_t* images, int64_t n, int in_h, int in_w, int in_channels,
+                            const float* mean3, const float* inv_std3, const float* pk, unsigned char* ws, size_t buf_bytes,
+                            float* out, hipStream_t s) {
+  const int kind = plan->compute;
+  uint16_t* x = reinterpret_cast<uint16_t*>(ws);
+  uint16_t* t1 = reinterpret_cast<uint16_t*>(ws + buf_bytes);
+  uint16_t* t2 = reinterpret_cast<uint16_t*>(ws + 2 * buf_bytes);
+  uint16_t* y = reinterpret_cast<uint16_t*>(ws + 3 * buf_bytes);
+  float* pooled = reinterpret_cast<float*>(ws + 4 * buf_bytes);
+  float* factors = pooled + align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) / sizeof(float);
+  int h = in_h, w = in_w;
+  int rc;
+  {  // stem: 3x3 / stride 2, 3 -> 64 (padded), SiLU, pre-processing fused
+    const EOp& o = plan->ops[0];
+    if (plan->ops.size() == 1 || o.cout_p != 64) { set_error("spr_effnet_forward: a 16-bit plan needs layers behind a 64-wide stem"); return SPR_ERR_UNSUPPORTED; }
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    const dim3 sgrid(static_cast<unsigned>(ceil_div(ho, kSTH) * ceil_div(wo, kSTW)), static_cast<unsigned>(n));
+    const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + o.w_off);
+    if (kind == SPR_F16)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(stem16_kernel<SPR_F16, 3, 2>), sgrid, dim3(kThreads), 0, s, images, h, w, in_channels,
+                         mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, pk + o.b_off, x, 2);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(stem16_kernel<SPR_BF16, 3, 2>), sgrid, dim3(kThreads), 0, s, images, h, w, in_channels,
+                         mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1], inv_std3[2], w16, pk + o.b_off, x, 2);
+    rc = check_launch("stem16_kernel");
+    if (rc != SPR_OK) return rc;
+    h = ho; w = wo;
+  }
+  const uint16_t* cur = x;
+  uint16_t* tmp[2] = {t1, t2};
+  int ti = 0;
+  const float* scale = nullptr;
+  for (size_t i = 1; i < plan->ops.size(); ++i) {
+    const EOp& o = plan->ops[i];
+    const bool last = i + 1 == plan->ops.size();
+    if (o.kind == 0) {
+      uint16_t* dst = o.block_end ? y : tmp[ti];
+      const uint16_t* res = o.res ? x : nullptr;
+      const float* sc = o.scaled ? scale : nullptr;
+      const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + o.w_off);
+      float* o32 = last ? out : nullptr;
+      if (o.ks == 3 && o.stride == 2)
+        rc = launch_gemm16_raw<3, 2>(kind, o.cin_p, o.cout_p, o.act, w16, pk + o.b_off, cur, n, h, w, res, dst, o32, sc, o.cout, s);
+      else if (o.ks == 3)
+        rc = launch_gemm16_raw<3, 1>(kind, o.cin_p, o.cout_p, o.act, w16, pk + o.b_off, cur, n, h, w, res, dst, o32, sc, o.cout, s);
+      else
+        rc = launch_gemm16_raw<1, 1>(kind, o.cin_p, o.cout_p, o.act, w16, pk + o.b_off, cur, n, h, w, res, dst, o32, sc, o.cout, s);
+      if (rc != SPR_OK) return rc;
+      if (o.stride == 2) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+      if (o.block_end) {
+        uint16_t* old = x; x = y; y = old;
+        cur = x;
+        ti = 0;
+      } else {
+        cur = dst;
+        ti ^= 1;
+      }
+    } else if (o.kind == 1) {
+      uint16_t* dst = tmp[ti];
+      const int ho = (h - 1) / o.stride + 1, wo = (w - 1) / o.stride + 1;
+      const size_t total = static_cast<size_t>(n) * ho * wo * (o.cin_p / 8);
+      const dim3 grid(static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 65535 * 16)));
+      if (kind == SPR_F16)
+        hipLaunchKernelGGL(enet_dw16_kernel<SPR_F16>, grid, dim3(kThreads), 0, s, cur, static_cast<int>(n), h, w, o.cin_p, o.stride,
+                           o.ks, pk + o.w_off, pk + o.b_off, dst);
+      else
+        hipLaunchKernelGGL(enet_dw16_kernel<SPR_BF16>, grid, dim3(kThreads), 0, s, cur, static_cast<int>(n), h, w, o.cin_p, o.stride,
+                           o.ks, pk + o.w_off, pk + o.b_off, dst);
+      rc = check_launch("enet_dw16_kernel");
+      if (rc != SPR_OK) return rc;
+      h = ho; w = wo;
+      cur = dst;
+      ti ^= 1;
+    } else {
+      const dim3 grid(o.cin_p / 64, static_cast<unsigned>(n));
+      if (kind == SPR_F16)
+        hipLaunchKernelGGL(enet_pool16_kernel<SPR_F16>, grid, dim3(kThreads), 0, s, cur, h * w, o.cin_p, pooled);
+      else
+        hipLaunchKernelGGL(enet_pool16_kernel<SPR_BF16>, grid, dim3(kThreads), 0, s, cur, h * w, o.cin_p, pooled);
+      rc = check_launch("enet_pool16_kernel");
+      if (rc != SPR_OK) return rc;
+      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n)), dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off,
+                         pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
+      rc = check_launch("enet_fc_kernel");
+      if (rc != SPR_OK) return rc;
+      scale = factors;
+    }
+  }
+  return SPR_OK;
+}
+
 extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, int64_t n, int32_t in_h, int32_t in_w,
                                   int32_t in_channels, const float* mean3, const float* inv_std3, const void* packed,
                                   void* workspace, float* out, spr_stream_t stream) {
@@ -1354,6 +1565,8 @@ extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, 
   const float* pk = static_cast<const float*>(packed);
   const size_t buf_bytes = align_up(effnet_buf_floats(plan, n, in_h, in_w) * sizeof(float), 256);
   unsigned char* ws = static_cast<unsigned char*>(workspace);
+  if (plan->compute != SPR_F32)
+    return effnet_forward16(plan, images, n, in_h, in_w, in_channels, mean3, inv_std3, pk, ws, buf_bytes, out, s);
   float* x = reinterpret_cast<float*>(ws);                    // block input
   float* t1 = reinterpret_cast<float*>(ws + buf_bytes);
   float* t2 = reinterpret_cast<float*>(ws + 2 * buf_bytes);

@@ -173,9 +173,9 @@ class Model:
         self.compute = str((config.get("mi355x") or {}).get("extractor_dtype", "float32") or "float32")
         if self.compute not in _COMPUTE:
             raise ValueError(f"[mi355x].extractor_dtype = {self.compute!r}: expected one of {sorted(_COMPUTE)}")
-        if self.compute != "float32" and (self.effnet or self.densenet):
-            raise NotImplementedError(f"{model_str}: the 16-bit matrix-core path is built for the VGG and ResNet50 extractors; "
-                                      "use [mi355x].extractor_dtype = \"float32\"")
+        if self.compute != "float32" and self.densenet:
+            raise NotImplementedError(f"{model_str}: the 16-bit matrix-core path is built for the VGG, ResNet50 and EfficientNet "
+                                      "extractors; use [mi355x].extractor_dtype = \"float32\"")
         handle = C.c_void_p()
         if self.densenet:
             self.lib.check(self.lib.spr_densenet_plan_create(self.block, C.byref(handle)))
@@ -186,7 +186,7 @@ class Model:
             self._set_densenet_parameters(parameters)
             return
         if self.effnet:
-            self.lib.check(self.lib.spr_effnet_plan_create(self.arch, self.block, C.byref(handle)))
+            self.lib.check(self.lib.spr_effnet_plan_create_ex(self.arch, self.block, _COMPUTE[self.compute], C.byref(handle)))
             self.handle = handle
             self.n_convs = self.lib.spr_effnet_num_ops(handle)
             if parameters is None:
@@ -245,7 +245,16 @@ class Model:
         if len(parameters) < len(ops):
             raise ValueError(f"{len(ops)} layers need parameters, got {len(parameters)}")
         packed = np.zeros(self.lib.spr_effnet_packed_bytes(self.handle) // 4, np.float32)
-        for op, p in zip(ops, parameters):
+        packed16 = packed.view(np.uint16)  # 16-bit plans: the convolutions' weights as float16 / bfloat16 bit patterns
+        half = self.compute != "float32"
+        if half and len(ops) < 2:
+            raise NotImplementedError("a 16-bit EfficientNet plan needs layers behind the stem (block >= 2)")
+
+        def bits16(a):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            return synth.bfloat16_bits(a) if self.compute == "bfloat16" else a.astype(np.float16).view(np.uint16)
+
+        for k_op, (op, p) in enumerate(zip(ops, parameters)):
             p = [np.asarray(t, dtype=np.float32) for t in p]
             if op["kind"] == 2:
                 w1, b1, w2, b2 = p
@@ -275,6 +284,24 @@ class Model:
                 continue
             if w.shape != (cout, cin, ks, ks):
                 raise ValueError(f"parameter shape {w.shape} does not match conv {cin}->{cout} {ks}x{ks}")
+            bb = np.zeros(cout_p, np.float32); bb[:cout] = b
+            if half and k_op == 0:
+                # the stem of a 16-bit plan: [k / 8][64][8], k = tap * 3 + plane, 27 real values of 32 (stem16_kernel)
+                ws = np.zeros((32, 64), np.float32)
+                ws[:27, :cout] = w.transpose(2, 3, 1, 0).reshape(27, cout)  # [ky][kx][c][n] -> k = (ky * 3 + kx) * 3 + c
+                ws = ws.reshape(4, 8, 64).transpose(0, 2, 1)               # [k / 8][n][k % 8]
+                packed16[2 * op["w_off"]:2 * op["w_off"] + ws.size] = bits16(ws).ravel()
+                packed[op["b_off"]:op["b_off"] + cout_p] = bb
+                continue
+            if half:
+                # [cout_p / 64][K / 64][64][64] with K index = tap * cin_p + c (conv_gemm16_kernel)
+                wk = np.zeros((cout_p, ks * ks, cin_p), np.float32)
+                wk[:cout, :, :cin] = w.reshape(cout, cin, ks * ks).transpose(0, 2, 1)
+                kk = ks * ks * cin_p
+                wk = wk.reshape(cout_p // 64, 64, kk // 64, 64).transpose(0, 2, 1, 3)
+                packed16[2 * op["w_off"]:2 * op["w_off"] + wk.size] = bits16(wk).ravel()
+                packed[op["b_off"]:op["b_off"] + cout_p] = bb
+                continue
             wp = np.zeros((cout_p, ks * ks, cin_p), np.float32)
             wp[:cout, :, :cin] = w.reshape(cout, cin, ks * ks).transpose(0, 2, 1)  # K index = tap * cin_p + c
             k = ks * ks * cin_p

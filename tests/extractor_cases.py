@@ -169,6 +169,36 @@ def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=Fa
     m.close()
 
 
+def check_effnet16(model_str, block, hw, device, lib, compute, n_images=1):
+    """An EfficientNet truncation on the 16-bit matrix cores (spr_effnet_plan_create_ex) against the oracle with the same
+    rounded weights and stored activations; tolerance as for the ResNet (dozens of layers: TOL16 for 99.9 % of the elements,
+    TOL16_DEEP for all)."""
+    from oracle import effnet_oracle
+
+    cfg = {"model": dict(CFG["model"], type=model_str), "comparison": CFG["comparison"], "mi355x": {"extractor_dtype": compute}}
+    m = network.Model(cfg, block, device=device, library=lib)
+    assert lib.spr_effnet_plan_compute(m.handle) == {"float16": 1, "bfloat16": 2}[compute]
+    ops = m.effnet_ops()
+    params = synth.effnet_parameters(1234, ops)
+    imgs = np.stack([synth.shoeprint_image(8, i, *hw) for i in range(n_images)])
+    got = device.to_host(m.extract_device(device.to_device(imgs)))
+    assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    for i in range(n_images):
+        ref = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std, m.bn_eps, compute=compute)
+        assert got[i].shape == ref.shape
+        scale = max(1.0, np.abs(ref).max())
+        err = np.abs(got[i] - ref)
+        # (the squeeze-excitation stages add rounding points - the mean of a stored tensor, the rounded product x * factor -
+        # and the truncated maps are small: measured under emulation, EfficientNetV2_S[:5] on a 40 x 32 image, float16:
+        # 2 of 768 elements beyond two steps, the largest at 1.8e-3 of the largest activation - as far from the oracle as the
+        # float32 network is)
+        assert np.mean(err > TOL16[compute] * scale) <= 5e-3, float(np.mean(err > TOL16[compute] * scale))
+        assert err.max() <= TOL16_DEEP[compute] * scale, float(err.max() / scale)
+        exact = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std, m.bn_eps)
+        assert np.abs(got[i] - exact).max() <= (0.1 if compute == "bfloat16" else 0.03) * max(1.0, np.abs(exact).max())
+    m.close()
+
+
 def check_densenet(block, hw, device, lib, n_images=2, tol=5e-5):
     """DenseNet_201 features[:block] against the torch-CPU oracle with the same seeded parameters; parity unpinned."""
     from oracle import densenet_oracle

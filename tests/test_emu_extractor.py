@@ -72,6 +72,15 @@ def test_emu_efficientnet_v2(model, block, hw, rgb):
     ec.check_effnet(model, block, hw, HostDevice(), emu_library(), n_images=1, rgb=rgb)
 
 
+@pytest.mark.parametrize("model,block,hw,compute", [("EfficientNetV2_M", 3, (40, 36), "bfloat16"), ("EfficientNetV2_S", 5, (40, 32), "float16"),
+                                                    ("EfficientNet_B1", 4, (40, 32), "bfloat16")])
+def test_emu_efficientnet_16bit(model, block, hw, compute):
+    """EfficientNet truncations on the 16-bit kernels under emulation: matrix-core stem (3x3 / stride 2, SiLU), FusedMBConv
+    and MBConv stages on the 16-bit GEMM kernel (SiLU in front of the residual sum, squeeze-excitation factors on the
+    operand), 16-bit depthwise convolutions (3x3 and, in the B-series, 5x5) and squeeze-excitation means."""
+    ec.check_effnet16(model, block, hw, HostDevice(), emu_library(), compute)
+
+
 @pytest.mark.parametrize("block,hw", [(1, (34, 32)), (3, (34, 32)), (5, (40, 36)), (6, (36, 40))])
 def test_emu_densenet201(block, hw):
     """DenseNet_201 truncations under emulation: the stem with and without norm0 / relu0 / pool0, the first dense block

@@ -549,3 +549,11 @@ def test_resnet50_on_the_16bit_matrix_cores(torch_dev, lib, compute, block, hw):
     import extractor_cases as ec
 
     ec.check_resnet50_16(block, hw, torch_dev, lib, compute)
+
+
+@pytest.mark.parametrize("model,block,hw,compute", [("EfficientNetV2_M", 6, (512, 256), "bfloat16"), ("EfficientNetV2_S", 7, (192, 128), "float16"),
+                                                    ("EfficientNet_B3", 6, (160, 96), "bfloat16"), ("EfficientNetV2_L", 9, (96, 64), "float16")])
+def test_efficientnet_on_the_16bit_matrix_cores(torch_dev, lib, model, block, hw, compute):
+    import extractor_cases as ec
+
+    ec.check_effnet16(model, block, hw, torch_dev, lib, compute)

@@ -16,5 +16,5 @@ e0.record()
 for _ in range(3): out = m.extract_device(imgs)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
-gflop = {("VGG16", 16): 48.77, ("VGG16", 23): 72.93, ("VGG16", 30): 80.18, ("ResNet50", 7): 17.13}.get((MODEL, BLOCK), 0.0)
+gflop = {("VGG16", 16): 48.77, ("VGG16", 23): 72.93, ("VGG16", 30): 80.18, ("ResNet50", 7): 17.13, ("EfficientNetV2_M", 6): 19.0}.get((MODEL, BLOCK), 0.0)
 print(f"{MODEL} {DTYPE} block {BLOCK}: {N} images {ms:.2f} ms -> {N/ms*1e3:.1f} images/s, {gflop*N/ms:.2f} TFLOP/s (conv MACs x2), out {tuple(out.shape)}")
