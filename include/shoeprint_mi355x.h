@@ -28,9 +28,10 @@
  *    network.py:241).
  *  - Thread safety: a plan may be used from one host thread at a time; different
  *    plans are independent.
- *  - One stream per plan at a time: a plan may own device scratch its kernels write (the workspace of the 384 x 192
- *    grid, the counters of the team schedule, the correction matrix of SPR_NCC_MFMA), so two spr_ncc_score calls on the
- *    same plan must be ordered - same stream, or an event between them; use one plan per stream to overlap layers.
+ *  - A plan may own device scratch its kernels write (the workspace of the 384 x 192 grid, the counters of the team
+ *    schedule, the correction matrix of SPR_NCC_MFMA).  Such a plan orders its own calls: spr_ncc_score / spr_ncc_maps record
+ *    an event behind their launches and a call arriving on another stream waits for it, so two streams sharing a plan
+ *    serialise on it instead of racing; use one plan per stream to overlap layers.
  *  - spr_*_plan_create / spr_*_plan_destroy are synchronous (hipMalloc / hipMemcpy / hipFree on the current device): create
  *    plans outside the hot path, with the device that will run them current.
  */

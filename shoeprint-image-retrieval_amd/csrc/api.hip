@@ -72,7 +72,35 @@ struct spr_ncc_plan {
   spr::FftWorkspace ws{nullptr, 0, nullptr};  // device: scratch of the "big" geometries (maps beyond LDS)
   float* six_ctab = nullptr;  // device: pre-twist table of the six-wave pair kernel
   float* mfma_x = nullptr;    // device: correction matrix of the matrix-core method's exact form (one call at a time per plan)
+  // A plan that owns device scratch its kernels write (mfma_x, team_sync, ws) orders its own calls: every scoring call
+  // records `done` behind its launches, and a call that arrives on ANOTHER stream waits for it first - two streams sharing a
+  // plan (one scorer, equal-shaped layers on separate streams) then serialise instead of racing on the scratch.
+  hipEvent_t done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+  bool team_mode = false;  // SPR_NCC_TEAM at plan creation: the team schedule's counters are written by the kernels
+  bool owns_scratch() const { return mfma_x || ws.base || (team_sync && team_mode); }
 };
+
+// before / after the launches of a scoring call on stream s
+static int plan_enter(spr_ncc_plan* plan, hipStream_t s) {
+  if (!plan->owns_scratch()) return SPR_OK;
+  if (!plan->done && hipEventCreateWithFlags(&plan->done, hipEventDisableTiming) != hipSuccess) {
+    spr::set_error("hipEventCreate failed");
+    return SPR_ERR_HIP;
+  }
+  if (plan->used && plan->last_stream != s && hipStreamWaitEvent(s, plan->done, 0) != hipSuccess) {
+    spr::set_error("hipStreamWaitEvent failed");
+    return SPR_ERR_HIP;
+  }
+  return SPR_OK;
+}
+static void plan_leave(spr_ncc_plan* plan, hipStream_t s) {
+  if (!plan->owns_scratch() || !plan->done) return;
+  (void)hipEventRecord(plan->done, s);
+  plan->last_stream = s;
+  plan->used = true;
+}
 
 using namespace spr;
 
@@ -199,6 +227,7 @@ extern "C" int spr_ncc_plan_create(const spr_ncc_shape* shape, spr_ncc_plan** pl
     }
     if (rc != SPR_OK) { spr_ncc_plan_destroy(p); return rc; }
   }
+  { const char* t = std::getenv("SPR_NCC_TEAM"); p->team_mode = t && t[0] == '1'; }
   *plan_out = p;
   return SPR_OK;
 }
@@ -211,6 +240,7 @@ extern "C" void spr_ncc_plan_destroy(spr_ncc_plan* plan) {
   if (plan->ws.base) (void)hipFree(plan->ws.base);
   if (plan->six_ctab) (void)hipFree(plan->six_ctab);
   if (plan->mfma_x) (void)hipFree(plan->mfma_x);
+  if (plan->done) (void)hipEventDestroy(plan->done);
   delete plan;
 }
 
@@ -262,20 +292,31 @@ extern "C" int spr_ncc_score(spr_ncc_plan* plan, const void* pq, int64_t nq, con
   if (!pq || !pg || !scores) { set_error("spr_ncc_score: null pointer"); return SPR_ERR_ARG; }
   if (nq > 65535 || ng > (1 << 24)) { set_error("spr_ncc_score: too many items in one call (chunk the gallery)"); return SPR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = plan_enter(plan, s);
+  if (rc != SPR_OK) return rc;
   if (plan->method == SPR_NCC_FFT)
-    return launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
-                           plan->tw_w, plan->team_sync, plan->ws, s);
-  if (plan->method == SPR_NCC_MFMA)
-    return launch_pair_mfma(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->mfma_x, s);
-  return launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
+    rc = launch_pair_fft(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->tw_h,
+                         plan->tw_w, plan->team_sync, plan->ws, s);
+  else if (plan->method == SPR_NCC_MFMA)
+    rc = launch_pair_mfma(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, plan->mfma_x, s);
+  else
+    rc = launch_pair_direct(plan->geom, pq, nq, pg, ng, scores, ld, col0, accumulate_max, nullptr, s);
+  plan_leave(plan, s);
+  return rc;
 }
 
 extern "C" int spr_ncc_maps(spr_ncc_plan* plan, const void* pq, const void* pg, float* maps_out, spr_stream_t stream) {
   if (!plan || !pq || !pg || !maps_out) { set_error("spr_ncc_maps: null pointer"); return SPR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = plan_enter(plan, s);
+  if (rc != SPR_OK) return rc;
   if (plan->method == SPR_NCC_FFT)
-    return launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w,
-                           plan->geom.big ? plan->team_sync : nullptr, plan->ws, s);
-  if (plan->method == SPR_NCC_MFMA) return launch_pair_mfma(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->mfma_x, s);
-  return launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
+    rc = launch_pair_fft(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->tw_h, plan->tw_w,
+                         plan->geom.big ? plan->team_sync : nullptr, plan->ws, s);
+  else if (plan->method == SPR_NCC_MFMA)
+    rc = launch_pair_mfma(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, plan->mfma_x, s);
+  else
+    rc = launch_pair_direct(plan->geom, pq, 1, pg, 1, nullptr, 1, 0, 0, maps_out, s);
+  plan_leave(plan, s);
+  return rc;
 }

@@ -246,6 +246,13 @@ static inline hipError_t hipMemset2DAsync(void* d, size_t pitch, int v, size_t w
   return hipSuccess;
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// events: the emulation runs every launch to completion on the calling thread, so ordering between streams is trivial
+typedef void* hipEvent_t;
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(1); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 // a pretend device of 16 CUs with room for 2 workgroups each (persistent-grid sizing)
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }

@@ -171,8 +171,16 @@ def check_effnet(model_str, block, hw, device, lib, n_images=2, tol=5e-5, rgb=Fa
 
 def check_effnet16(model_str, block, hw, device, lib, compute, n_images=1):
     """An EfficientNet truncation on the 16-bit matrix cores (spr_effnet_plan_create_ex) against the oracle with the same
-    rounded weights and stored activations; tolerance as for the ResNet (dozens of layers: TOL16 for 99.9 % of the elements,
-    TOL16_DEEP for all)."""
+    rounded weights and stored activations.
+
+    Through up to ~110 layers with SiLU and squeeze-excitation two correct 16-bit evaluations that only ORDER their float32
+    additions differently drift apart: a stored activation on a rounding boundary lands one step apart, and everything behind
+    it carries and amplifies that.  Measured under the bit-exact emulation, EfficientNetV2_M[:6]: rms(kernel - oracle16) =
+    0.77 x rms(oracle16 - float32 network) in bfloat16 and 0.79 x in float16 - the distance scales with the step of the type
+    (so it is rounding, not a wrong operation) and is as large as the 16-bit oracle's own distance from the float32 network.
+    The check is therefore statistical, and weaker than the VGG one: the kernel must be (1) no farther from the 16-bit oracle
+    than 1.25 x the oracle is from the float32 network, and (2) no farther from the float32 network than 1.5 x the oracle is
+    (rms over the output; maxima within 2 x); shallow truncations (few rounding points) additionally hold TOL16_DEEP."""
     from oracle import effnet_oracle
 
     cfg = {"model": dict(CFG["model"], type=model_str), "comparison": CFG["comparison"], "mi355x": {"extractor_dtype": compute}}
@@ -183,19 +191,19 @@ def check_effnet16(model_str, block, hw, device, lib, compute, n_images=1):
     imgs = np.stack([synth.shoeprint_image(8, i, *hw) for i in range(n_images)])
     got = device.to_host(m.extract_device(device.to_device(imgs)))
     assert got.dtype == np.float32 and got.shape[1:] == m.output_shape(*hw)
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
     for i in range(n_images):
         ref = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std, m.bn_eps, compute=compute)
-        assert got[i].shape == ref.shape
-        scale = max(1.0, np.abs(ref).max())
-        err = np.abs(got[i] - ref)
-        # (the squeeze-excitation stages add rounding points - the mean of a stored tensor, the rounded product x * factor -
-        # and the truncated maps are small: measured under emulation, EfficientNetV2_S[:5] on a 40 x 32 image, float16:
-        # 2 of 768 elements beyond two steps, the largest at 1.8e-3 of the largest activation - as far from the oracle as the
-        # float32 network is)
-        assert np.mean(err > TOL16[compute] * scale) <= 5e-3, float(np.mean(err > TOL16[compute] * scale))
-        assert err.max() <= TOL16_DEEP[compute] * scale, float(err.max() / scale)
         exact = effnet_oracle.get_feature_maps(imgs[i], ops, params, m.mean, m.std, m.bn_eps)
-        assert np.abs(got[i] - exact).max() <= (0.1 if compute == "bfloat16" else 0.03) * max(1.0, np.abs(exact).max())
+        assert got[i].shape == ref.shape
+        scale = max(1.0, np.abs(exact).max())
+        step = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}[compute] * scale  # one step of the type at the largest activation
+        noise_rms, noise_max = max(rms(ref - exact), 0.25 * step), max(np.abs(ref - exact).max(), step)
+        assert rms(got[i] - ref) <= 1.25 * noise_rms, (rms(got[i] - ref), noise_rms)
+        assert rms(got[i] - exact) <= 1.5 * noise_rms, (rms(got[i] - exact), noise_rms)
+        assert np.abs(got[i] - ref).max() <= 2.0 * noise_max and np.abs(got[i] - exact).max() <= 2.0 * noise_max
+        if len(ops) <= 30:
+            assert np.abs(got[i] - ref).max() <= TOL16_DEEP[compute] * scale
     m.close()
 
 
