@@ -797,10 +797,20 @@ enet_fc_kernel(const float* __restrict__ pooled, int C, int sq, const float* __r
     __syncthreads();
     // (sq <= 256 for every model of the list: one sweep; the second phase below reads hid[0 .. sq))
   }
-  for (int c = tid; c < C; c += kThreads) {
-    float s = b2[c];
-    for (int j = 0; j < sq; ++j) s = fmaf(w2[static_cast<size_t>(c) * sq + j], hid[j], s);
-    scale[img * C + c] = 1.0f / (1.0f + expf(-s));
+  // second layer: one channel per work-item, grid.y blocks of 256 channels (every block repeats the cheap first layer); the
+  // row of w2 is read four values at a time so that four loads are in flight instead of one per dependent fma
+  const int c = static_cast<int>(blockIdx.y) * kThreads + tid;
+  if (c < C) {
+    const float* row = w2 + static_cast<size_t>(c) * sq;
+    float s0 = b2[c], s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int j = 0;
+    for (; j + 4 <= sq; j += 4) {
+      const float a0 = row[j], a1 = row[j + 1], a2 = row[j + 2], a3 = row[j + 3];
+      s0 = fmaf(a0, hid[j], s0); s1 = fmaf(a1, hid[j + 1], s1); s2 = fmaf(a2, hid[j + 2], s2); s3 = fmaf(a3, hid[j + 3], s3);
+    }
+    for (; j < sq; ++j) s0 = fmaf(row[j], hid[j], s0);
+    const float t = (s0 + s1) + (s2 + s3);
+    scale[img * C + c] = 1.0f / (1.0f + expf(-t));
   }
 }
 
@@ -1565,8 +1575,8 @@ static int effnet_forward16(const spr_effnet_plan* plan, const uint8_t* images, 
         hipLaunchKernelGGL(enet_pool16_kernel<SPR_BF16>, grid, dim3(kThreads), 0, s, cur, h * w, o.cin_p, pooled);
       rc = check_launch("enet_pool16_kernel");
       if (rc != SPR_OK) return rc;
-      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n)), dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off,
-                         pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
+      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n), static_cast<unsigned>(ceil_div(o.cin_p, kThreads))),
+                         dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off, pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
       rc = check_launch("enet_fc_kernel");
       if (rc != SPR_OK) return rc;
       scale = factors;
@@ -1644,8 +1654,8 @@ extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, 
                          pooled);
       rc = check_launch("enet_pool_kernel");
       if (rc != SPR_OK) return rc;
-      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n)), dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off,
-                         pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
+      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n), static_cast<unsigned>(ceil_div(o.cin_p, kThreads))),
+                         dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off, pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
       rc = check_launch("enet_fc_kernel");
       if (rc != SPR_OK) return rc;
       scale = factors;
