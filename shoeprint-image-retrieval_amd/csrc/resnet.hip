@@ -769,49 +769,77 @@ enet_pool_kernel(const float* __restrict__ in, int HW, int C, float* __restrict_
   if (r == 0) pooled[img * C + blockIdx.x * 64 + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / static_cast<float>(HW);
 }
 
-// step 2: scale[c] = sigmoid(W2 SiLU(W1 pooled + b1) + b2).  grid = images; w1 [sq][C], w2 [C][sq] (C padded, sq real).
-// Hidden unit j = a dot product over C: the whole workgroup sweeps row j of w1 (coalesced), wave-shuffle + LDS reduction - a
-// work-item per hidden unit walking its row alone took 93 us per call at C = 1056 (a quarter of a 16-bit forward pass).
+// step 2: scale[img][c] = sigmoid(W2 SiLU(W1 pooled[img] + b1) + b2); w1 [sq][C], w2 [C][sq] (C padded, sq real).  Two small
+// kernels over ALL images, each weight row read once: with a workgroup per image walking the hidden units one after another
+// every unit paid a cold trip to memory for its row (measured: 76 - 93 us per call at C = 1056, a quarter of a 16-bit pass).
+// first layer, grid = hidden units: the workgroup holds row j of w1 in registers and sweeps the images
 __global__ void __launch_bounds__(kThreads)
-enet_fc_kernel(const float* __restrict__ pooled, int C, int sq, const float* __restrict__ w1, const float* __restrict__ b1,
-               const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ scale) {
-  __shared__ float hid[256];
-  __shared__ float part[256][4];
+enet_fc1_kernel(const float* __restrict__ pooled, int n_img, int C, int sq, const float* __restrict__ w1,
+                const float* __restrict__ b1, float* __restrict__ hid) {
+  __shared__ float part[4];
   const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
-  const size_t img = blockIdx.x;
-  const float* pv = pooled + img * C;
-  for (int j0 = 0; j0 < sq; j0 += 256) {
-    const int jn = sq - j0 < 256 ? sq - j0 : 256;
-    for (int j = 0; j < jn; ++j) {
-      const float* row = w1 + static_cast<size_t>(j0 + j) * C;
-      float s = 0.0f;
-      for (int c = tid; c < C; c += kThreads) s = fmaf(row[c], pv[c], s);
-      for (int m = 32; m >= 1; m >>= 1) s += shfl_xor(s, m);
-      if (lane == 0) part[j][wave] = s;
-    }
+  const int j = static_cast<int>(blockIdx.x);
+  constexpr int kMaxPer = 16;  // C <= 4096
+  float wr[kMaxPer];
+#pragma unroll
+  for (int k = 0; k < kMaxPer; ++k) wr[k] = tid + k * kThreads < C ? w1[static_cast<size_t>(j) * C + tid + k * kThreads] : 0.0f;
+  const float bj = b1[j];
+  for (int img = 0; img < n_img; ++img) {
+    const float* pv = pooled + static_cast<size_t>(img) * C;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxPer; ++k)
+      if (tid + k * kThreads < C) s = fmaf(wr[k], pv[tid + k * kThreads], s);
+    for (int m = 32; m >= 1; m >>= 1) s += shfl_xor(s, m);
+    __syncthreads();  // (part is free again)
+    if (lane == 0) part[wave] = s;
     __syncthreads();
-    if (tid < jn) {
-      const float v = b1[j0 + tid] + ((part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]));
-      hid[tid] = v / (1.0f + expf(-v));
+    if (tid == 0) {
+      const float v = bj + ((part[0] + part[1]) + (part[2] + part[3]));
+      hid[static_cast<size_t>(img) * sq + j] = v / (1.0f + expf(-v));
     }
-    __syncthreads();
-    // (sq <= 256 for every model of the list: one sweep; the second phase below reads hid[0 .. sq))
   }
-  // second layer: one channel per work-item, grid.y blocks of 256 channels (every block repeats the cheap first layer); the
-  // row of w2 is read four values at a time so that four loads are in flight instead of one per dependent fma
-  const int c = static_cast<int>(blockIdx.y) * kThreads + tid;
-  if (c < C) {
-    const float* row = w2 + static_cast<size_t>(c) * sq;
-    float s0 = b2[c], s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+}
+// second layer, grid = blocks of 256 channels: a work-item holds row c of w2 and sweeps the images
+__global__ void __launch_bounds__(kThreads)
+enet_fc2_kernel(const float* __restrict__ hid, int n_img, int C, int sq, const float* __restrict__ w2,
+                const float* __restrict__ b2, float* __restrict__ scale) {
+  float* hs = reinterpret_cast<float*>(dyn_lds());  // hid of all images: n_img * sq floats
+  const int tid = static_cast<int>(threadIdx.x);
+  for (int i = tid; i < n_img * sq; i += kThreads) hs[i] = hid[i];
+  __syncthreads();
+  const int c = static_cast<int>(blockIdx.x) * kThreads + tid;
+  if (c >= C) return;
+  const float* row = w2 + static_cast<size_t>(c) * sq;
+  const float bc = b2[c];
+  for (int img = 0; img < n_img; ++img) {
+    const float* h = hs + img * sq;
+    float s0 = bc, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int j = 0;
     for (; j + 4 <= sq; j += 4) {
-      const float a0 = row[j], a1 = row[j + 1], a2 = row[j + 2], a3 = row[j + 3];
-      s0 = fmaf(a0, hid[j], s0); s1 = fmaf(a1, hid[j + 1], s1); s2 = fmaf(a2, hid[j + 2], s2); s3 = fmaf(a3, hid[j + 3], s3);
+      s0 = fmaf(row[j], h[j], s0); s1 = fmaf(row[j + 1], h[j + 1], s1);
+      s2 = fmaf(row[j + 2], h[j + 2], s2); s3 = fmaf(row[j + 3], h[j + 3], s3);
     }
-    for (; j < sq; ++j) s0 = fmaf(row[j], hid[j], s0);
+    for (; j < sq; ++j) s0 = fmaf(row[j], h[j], s0);
     const float t = (s0 + s1) + (s2 + s3);
-    scale[img * C + c] = 1.0f / (1.0f + expf(-t));
+    scale[static_cast<size_t>(img) * C + c] = 1.0f / (1.0f + expf(-t));
   }
+}
+// both layers; `hid` = n_img * sq floats of scratch
+static int launch_enet_fc(const float* pooled, int64_t n, int C, int sq, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* hid, float* scale, hipStream_t s) {
+  if (C > 16 * kThreads || static_cast<size_t>(n) * sq * sizeof(float) > 60 * 1024) {
+    set_error("squeeze-excitation: %d channels / %lld images x %d hidden units exceed the fc kernels' limits", C,
+              static_cast<long long>(n), sq);
+    return SPR_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(enet_fc1_kernel, dim3(static_cast<unsigned>(sq)), dim3(kThreads), 0, s, pooled, static_cast<int>(n), C, sq,
+                     w1, b1, hid);
+  int rc = check_launch("enet_fc1_kernel");
+  if (rc != SPR_OK) return rc;
+  hipLaunchKernelGGL(enet_fc2_kernel, dim3(static_cast<unsigned>(ceil_div(C, kThreads))), dim3(kThreads),
+                     static_cast<size_t>(n) * sq * sizeof(float), s, hid, static_cast<int>(n), C, sq, w2, b2, scale);
+  return check_launch("enet_fc2_kernel");
 }
 
 // ---- 16-bit plans (spr_effnet_plan_create_ex): activations NHWC float16 / bfloat16, the same padding to 64 channels
@@ -1474,7 +1502,9 @@ static size_t effnet_buf_floats(const spr_effnet_plan* plan, int64_t n, int in_h
 extern "C" size_t spr_effnet_workspace_bytes(const spr_effnet_plan* plan, int64_t n, int32_t in_h, int32_t in_w) {
   if (!plan || n < 0) return 0;
   const size_t buf = align_up(effnet_buf_floats(plan, n, in_h, in_w) * sizeof(float), 256);
-  return 4 * buf + 2 * align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256);
+  // four activation buffers, the squeeze-excitation means and factors, and the hidden units of its first layer
+  return 4 * buf + 2 * align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) +
+         align_up(static_cast<size_t>(n) * 256 * sizeof(float), 256);
 }
 
 template <int KS, int STRIDE>
@@ -1504,6 +1534,7 @@ static int effnet_forward16(const spr_effnet_plan* plan, const uint8_t* images, 
   uint16_t* y = reinterpret_cast<uint16_t*>(ws + 3 * buf_bytes);
   float* pooled = reinterpret_cast<float*>(ws + 4 * buf_bytes);
   float* factors = pooled + align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) / sizeof(float);
+  float* hidden = factors + align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) / sizeof(float);
   int h = in_h, w = in_w;
   int rc;
   {  // stem: 3x3 / stride 2, 3 -> 64 (padded), SiLU, pre-processing fused
@@ -1575,9 +1606,7 @@ static int effnet_forward16(const spr_effnet_plan* plan, const uint8_t* images, 
         hipLaunchKernelGGL(enet_pool16_kernel<SPR_BF16>, grid, dim3(kThreads), 0, s, cur, h * w, o.cin_p, pooled);
       rc = check_launch("enet_pool16_kernel");
       if (rc != SPR_OK) return rc;
-      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n), static_cast<unsigned>(ceil_div(o.cin_p, kThreads))),
-                         dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off, pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
-      rc = check_launch("enet_fc_kernel");
+      rc = launch_enet_fc(pooled, n, o.cin_p, o.sq, pk + o.w_off, pk + o.b_off, pk + o.w2_off, pk + o.b2_off, hidden, factors, s);
       if (rc != SPR_OK) return rc;
       scale = factors;
     }
@@ -1607,6 +1636,7 @@ extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, 
   float* y = reinterpret_cast<float*>(ws + 3 * buf_bytes);    // block output
   float* pooled = reinterpret_cast<float*>(ws + 4 * buf_bytes);
   float* factors = pooled + align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) / sizeof(float);
+  float* hidden = factors + align_up(static_cast<size_t>(n) * plan->max_expand_p * sizeof(float), 256) / sizeof(float);
   const size_t pixels = static_cast<size_t>(n) * in_h * in_w;
   hipLaunchKernelGGL(enet_input_kernel, dim3(static_cast<unsigned>(std::min<size_t>((pixels + kThreads - 1) / kThreads, 65535 * 16))),
                      dim3(kThreads), 0, s, images, pixels, in_channels, mean3[0], mean3[1], mean3[2], inv_std3[0], inv_std3[1],
@@ -1654,9 +1684,7 @@ extern "C" int spr_effnet_forward(spr_effnet_plan* plan, const uint8_t* images, 
                          pooled);
       rc = check_launch("enet_pool_kernel");
       if (rc != SPR_OK) return rc;
-      hipLaunchKernelGGL(enet_fc_kernel, dim3(static_cast<unsigned>(n), static_cast<unsigned>(ceil_div(o.cin_p, kThreads))),
-                         dim3(kThreads), 0, s, pooled, o.cin_p, o.sq, pk + o.w_off, pk + o.b_off, pk + o.w2_off, pk + o.b2_off, factors);
-      rc = check_launch("enet_fc_kernel");
+      rc = launch_enet_fc(pooled, n, o.cin_p, o.sq, pk + o.w_off, pk + o.b_off, pk + o.w2_off, pk + o.b2_off, hidden, factors, s);
       if (rc != SPR_OK) return rc;
       scale = factors;
     }
