@@ -770,75 +770,63 @@ enet_pool_kernel(const float* __restrict__ in, int HW, int C, float* __restrict_
 }
 
 // step 2: scale[img][c] = sigmoid(W2 SiLU(W1 pooled[img] + b1) + b2); w1 [sq][C], w2 [C][sq] (C padded, sq real).  Two small
-// kernels over ALL images, each weight row read once: with a workgroup per image walking the hidden units one after another
-// every unit paid a cold trip to memory for its row (measured: 76 - 93 us per call at C = 1056, a quarter of a 16-bit pass).
-// first layer, grid = hidden units: the workgroup holds row j of w1 in registers and sweeps the images
+// kernels with one unit of work per (image, output): a workgroup per image walking its outputs one after another paid a
+// trip to memory per output (measured: 76 - 93 us per call at C = 1056, a quarter of a 16-bit forward pass).
+// first layer: one WAVE per (image, hidden unit j): a dot product over C, lanes sweep the channels
 __global__ void __launch_bounds__(kThreads)
 enet_fc1_kernel(const float* __restrict__ pooled, int n_img, int C, int sq, const float* __restrict__ w1,
                 const float* __restrict__ b1, float* __restrict__ hid) {
-  __shared__ float part[4];
-  const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
-  const int j = static_cast<int>(blockIdx.x);
-  constexpr int kMaxPer = 16;  // C <= 4096
-  float wr[kMaxPer];
-#pragma unroll
-  for (int k = 0; k < kMaxPer; ++k) wr[k] = tid + k * kThreads < C ? w1[static_cast<size_t>(j) * C + tid + k * kThreads] : 0.0f;
-  const float bj = b1[j];
-  for (int img = 0; img < n_img; ++img) {
-    const float* pv = pooled + static_cast<size_t>(img) * C;
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kMaxPer; ++k)
-      if (tid + k * kThreads < C) s = fmaf(wr[k], pv[tid + k * kThreads], s);
-    for (int m = 32; m >= 1; m >>= 1) s += shfl_xor(s, m);
-    __syncthreads();  // (part is free again)
-    if (lane == 0) part[wave] = s;
-    __syncthreads();
-    if (tid == 0) {
-      const float v = bj + ((part[0] + part[1]) + (part[2] + part[3]));
-      hid[static_cast<size_t>(img) * sq + j] = v / (1.0f + expf(-v));
-    }
+  const int tid = static_cast<int>(threadIdx.x), lane = tid & 63;
+  const long long unit = static_cast<long long>(blockIdx.x) * (kThreads / 64) + (tid >> 6);
+  if (unit >= static_cast<long long>(n_img) * sq) return;  // (whole waves leave: no barrier below)
+  const int img = static_cast<int>(unit / sq), j = static_cast<int>(unit - static_cast<long long>(img) * sq);
+  const float* row = w1 + static_cast<size_t>(j) * C;
+  const float* pv = pooled + static_cast<size_t>(img) * C;
+  float s0 = 0.0f, s1 = 0.0f;
+  int c = lane;
+  for (; c + 64 < C; c += 128) {
+    s0 = fmaf(row[c], pv[c], s0);
+    s1 = fmaf(row[c + 64], pv[c + 64], s1);
+  }
+  if (c < C) s0 = fmaf(row[c], pv[c], s0);
+  float s = s0 + s1;
+  for (int m = 32; m >= 1; m >>= 1) s += shfl_xor(s, m);
+  if (lane == 0) {
+    const float v = b1[j] + s;
+    hid[static_cast<size_t>(img) * sq + j] = v / (1.0f + expf(-v));
   }
 }
-// second layer, grid = blocks of 256 channels: a work-item holds row c of w2 and sweeps the images
+// second layer, grid = (blocks of 64 channels, images): four work-items per channel take every fourth hidden unit
 __global__ void __launch_bounds__(kThreads)
-enet_fc2_kernel(const float* __restrict__ hid, int n_img, int C, int sq, const float* __restrict__ w2,
-                const float* __restrict__ b2, float* __restrict__ scale) {
-  float* hs = reinterpret_cast<float*>(dyn_lds());  // hid of all images: n_img * sq floats
-  const int tid = static_cast<int>(threadIdx.x);
-  for (int i = tid; i < n_img * sq; i += kThreads) hs[i] = hid[i];
+enet_fc2_kernel(const float* __restrict__ hid, int C, int sq, const float* __restrict__ w2, const float* __restrict__ b2,
+                float* __restrict__ scale) {
+  __shared__ float part[4][64];
+  const int tid = static_cast<int>(threadIdx.x), cl = tid & 63, r = tid >> 6;
+  const size_t img = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 64 + cl;
+  const float* h = hid + img * sq;
+  float s = 0.0f;
+  if (c < C) {
+    const float* row = w2 + static_cast<size_t>(c) * sq;
+    for (int j = r; j < sq; j += 4) s = fmaf(row[j], h[j], s);
+  }
+  part[r][cl] = s;
   __syncthreads();
-  const int c = static_cast<int>(blockIdx.x) * kThreads + tid;
-  if (c >= C) return;
-  const float* row = w2 + static_cast<size_t>(c) * sq;
-  const float bc = b2[c];
-  for (int img = 0; img < n_img; ++img) {
-    const float* h = hs + img * sq;
-    float s0 = bc, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int j = 0;
-    for (; j + 4 <= sq; j += 4) {
-      s0 = fmaf(row[j], h[j], s0); s1 = fmaf(row[j + 1], h[j + 1], s1);
-      s2 = fmaf(row[j + 2], h[j + 2], s2); s3 = fmaf(row[j + 3], h[j + 3], s3);
-    }
-    for (; j < sq; ++j) s0 = fmaf(row[j], h[j], s0);
-    const float t = (s0 + s1) + (s2 + s3);
-    scale[static_cast<size_t>(img) * C + c] = 1.0f / (1.0f + expf(-t));
+  if (r == 0 && c < C) {
+    const float t = b2[c] + ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+    scale[img * C + c] = 1.0f / (1.0f + expf(-t));
   }
 }
 // both layers; `hid` = n_img * sq floats of scratch
 static int launch_enet_fc(const float* pooled, int64_t n, int C, int sq, const float* w1, const float* b1, const float* w2,
                           const float* b2, float* hid, float* scale, hipStream_t s) {
-  if (C > 16 * kThreads || static_cast<size_t>(n) * sq * sizeof(float) > 60 * 1024) {
-    set_error("squeeze-excitation: %d channels / %lld images x %d hidden units exceed the fc kernels' limits", C,
-              static_cast<long long>(n), sq);
-    return SPR_ERR_UNSUPPORTED;
-  }
-  hipLaunchKernelGGL(enet_fc1_kernel, dim3(static_cast<unsigned>(sq)), dim3(kThreads), 0, s, pooled, static_cast<int>(n), C, sq,
-                     w1, b1, hid);
+  const long long units = static_cast<long long>(n) * sq;
+  hipLaunchKernelGGL(enet_fc1_kernel, dim3(static_cast<unsigned>((units + 3) / 4)), dim3(kThreads), 0, s, pooled,
+                     static_cast<int>(n), C, sq, w1, b1, hid);
   int rc = check_launch("enet_fc1_kernel");
   if (rc != SPR_OK) return rc;
-  hipLaunchKernelGGL(enet_fc2_kernel, dim3(static_cast<unsigned>(ceil_div(C, kThreads))), dim3(kThreads),
-                     static_cast<size_t>(n) * sq * sizeof(float), s, hid, static_cast<int>(n), C, sq, w2, b2, scale);
+  hipLaunchKernelGGL(enet_fc2_kernel, dim3(static_cast<unsigned>(ceil_div(C, 64)), static_cast<unsigned>(n)), dim3(kThreads), 0, s,
+                     hid, C, sq, w2, b2, scale);
   return check_launch("enet_fc2_kernel");
 }
 
