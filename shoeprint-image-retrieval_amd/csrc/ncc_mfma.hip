@@ -138,6 +138,16 @@ __device__ __forceinline__ float from_storage(unsigned bits, int dtype) {
   return static_cast<float>(c.h);
 }
 
+// LDS of the prep kernel: the centred map (template or search map, whichever is larger) and two float64 summed-area tables.
+// The equal-size instance holds exactly its 28 x 12 map (7.4 KB per wave-sized workgroup: 21 of them share a CU).
+template <class M>
+struct MPrepSizes {
+  static constexpr bool kFixed = M::FH == M::TH;
+  static constexpr int kMaxPix = kFixed ? M::NPOS : (M::FH * 16 > M::NPOS ? M::FH * 16 : M::NPOS);
+  static constexpr int kSatElems = kFixed ? (M::TH + 1) * (M::TW + 1)
+                                          : ((M::FH + 1) * 17 > (M::TH + 1) * (M::TW + 1) ? (M::FH + 1) * 17 : (M::TH + 1) * (M::TW + 1));
+};
+
 // ---- preparation: grid = (channels, items) ---------------------------------------------------------------------------
 // EXACT form: the search map enters the matrix cores RAW (bf16 as stored: one MFMA per tile step, every product exact) and
 // the centring of both sides becomes two corrections of the raw product R[q,p] = sum_tap t[q,tap] Iz[p + tap]:
@@ -145,15 +155,16 @@ __device__ __forceinline__ float from_storage(unsigned bits, int dtype) {
 //                                                          inside the map at position p, SI = window sum of the raw map
 // The last term is a weight of the pair kernel's epilogue like before (b * SI in place of b * S1); the middle one is a
 // contraction over the channels per position, X[q,g,p] = sum_c (a St0)[q,c,p] * (b mean(I))[g,c,p], left to corr_mfma_kernel.
-template <class M, bool EXACT>
+template <class M, bool EXACT, bool FIXED>
 __global__ void __launch_bounds__(kThreads)
 prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigned char* __restrict__ prepared,
                  size_t item_bytes) {
-  // Real sizes (cropped): template th x tw inside the FH x 16 frame, search map ih x iw inside the TH x TW frame.
-  const int th = g.th, tw = g.tw, ih = g.ih, iw = g.iw;
+  // Real sizes (cropped): template th x tw inside the FH x 16 frame, search map ih x iw inside the TH x TW frame.  FIXED (the
+  // equal-size instance: template = map = the frame of positions): compile-time constants - with run-time sizes the kernel took
+  // 51 ms instead of 31 for BASELINE config 3's gallery.
+  const int th = FIXED ? M::TH : g.th, tw = FIXED ? M::TW : g.tw, ih = FIXED ? M::TH : g.ih, iw = FIXED ? M::TW : g.iw;
   const int fy = M::CY - th / 2, fx = M::CX - tw / 2;  // frame position of template tap (0, 0)
-  constexpr int kMaxPix = M::FH * 16 > M::NPOS ? M::FH * 16 : M::NPOS;
-  constexpr int kSatElems = (M::FH + 1) * 17 > (M::TH + 1) * (M::TW + 1) ? (M::FH + 1) * 17 : (M::TH + 1) * (M::TW + 1);
+  constexpr int kMaxPix = MPrepSizes<M>::kMaxPix, kSatElems = MPrepSizes<M>::kSatElems;
   unsigned char* lds = dyn_lds();
   double* red = reinterpret_cast<double*>(lds);
   float* x0 = reinterpret_cast<float*>(lds + 64);
@@ -721,11 +732,11 @@ size_t mfma_workspace_bytes(const NccGeom& g) {
 
 template <class M>
 static int launch_prep_mfma_m(const NccGeom& g, bool is_query, const void* maps, int64_t n, void* prepared, hipStream_t stream) {
-  constexpr int kMaxPix = M::FH * 16 > M::NPOS ? M::FH * 16 : M::NPOS;
-  constexpr int kSatElems = (M::FH + 1) * 17 > (M::TH + 1) * (M::TW + 1) ? (M::FH + 1) * 17 : (M::TH + 1) * (M::TW + 1);
+  constexpr int kMaxPix = MPrepSizes<M>::kMaxPix, kSatElems = MPrepSizes<M>::kSatElems;
   const size_t lds = align_up(64 + sizeof(float) * kMaxPix, 16) + 2 * sizeof(double) * kSatElems;
   const size_t item_bytes = is_query ? mfma_query_item_bytes(g) : mfma_gallery_item_bytes(g);
-  auto kernel = g.mfma_exact ? prep_mfma_kernel<M, true> : prep_mfma_kernel<M, false>;
+  constexpr bool kFixed = M::FH == M::TH;  // (the equal-size instance is only chosen for template = map = frame)
+  auto kernel = g.mfma_exact ? prep_mfma_kernel<M, true, kFixed> : prep_mfma_kernel<M, false, kFixed>;
   // one wave per (item, channel): maps of 336 pixels leave a 256-lane workgroup waiting at its ~20 barriers
   hipLaunchKernelGGL(kernel, dim3(g.channels, static_cast<unsigned>(n)), dim3(64), lds, stream, g, is_query ? 1 : 0, maps,
                      static_cast<unsigned char*>(prepared), item_bytes);
