@@ -1556,10 +1556,6 @@ static int effnet_forward16(const spr_effnet_plan* plan, const uint8_t* images, 
       float* o32 = last ? out : nullptr;
       if (o.ks == 3 && o.stride == 2)
         rc = launch_gemm16_raw<3, 2>(kind, o.cin_p, o.cout_p, o.act, w16, pk + o.b_off, cur, n, h, w, res, dst, o32, sc, o.cout, s);
-      else if (o.ks == 3 && !last && !sc)
-        // 3x3 / stride 1 (the FusedMBConv stages): the patch kernel of vgg_conv.hip on the same packed weights (nine taps per
-        // staged patch instead of a 64-deep GEMM chunk per tap)
-        rc = launch_conv16_3x3(kind, cur, n, h, w, o.cin_p, o.cout_p, w16, pk + o.b_off, o.act, dst, s, 1, res);
       else if (o.ks == 3)
         rc = launch_gemm16_raw<3, 1>(kind, o.cin_p, o.cout_p, o.act, w16, pk + o.b_off, cur, n, h, w, res, dst, o32, sc, o.cout, s);
       else

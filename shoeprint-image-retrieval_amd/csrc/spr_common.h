@@ -108,11 +108,8 @@ size_t prepared_gallery_item_bytes(const NccGeom& g, int method);
 // 16-bit 3x3 / stride 1 convolution of vgg_conv.hip, shared with the ResNet plans (NHWC 16-bit in / out)
 int pack_conv16_3x3(int kind, const float* w, const float* b, float* packed, size_t w_off, size_t b_off, int cin, int cout,
                     hipStream_t s);
-// relu: 0 none, 1 ReLU, 2 SiLU; gemm_layout: weights packed for conv_gemm16_kernel (cin a multiple of 64); res: NHWC 16-bit
-// tensor added behind the activation, or null
 int launch_conv16_3x3(int kind, const uint16_t* in, int64_t n, int h, int w, int cin, int cout, const uint16_t* w16,
-                      const float* bias, int relu, uint16_t* out, hipStream_t s, int gemm_layout = 0,
-                      const uint16_t* res = nullptr);
+                      const float* bias, int relu, uint16_t* out, hipStream_t s);
 
 // first convolution of a plain VGG in a 16-bit plan (resnet.hip: the stem kernel's 3x3 / stride 1 instance)
 int pack_first16(int kind, const float* w, const float* b, float* packed, size_t w_off, size_t b_off, hipStream_t s);

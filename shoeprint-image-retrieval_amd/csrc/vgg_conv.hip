@@ -337,10 +337,7 @@ template <int KIND>
 __global__ void __launch_bounds__(kThreads, 2)
 conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, const uint16_t* __restrict__ wts,
               const float* __restrict__ bias, int relu, int pool, int nchw, float* __restrict__ out,
-              float* __restrict__ tap, int gemm_layout, const uint16_t* __restrict__ res) {
-  // relu: activation code (0 none, 1 ReLU, 2 SiLU - in front of the residual sum, as the EfficientNet blocks have it);
-  // gemm_layout: the weights lie as conv_gemm16_kernel takes them ([cout/64][K/64][n: 64][k: 64], K = tap * cin + c; cin a
-  // multiple of 64) instead of this kernel's own packing; res: NHWC 16-bit tensor added to the (un-pooled, staged) result
+              float* __restrict__ tap) {
   unsigned char* lds = dyn_lds();
   float* patch = reinterpret_cast<float*>(lds);  // [18*18][16 dwords]: dword = two channels
   float* wl = patch + kPatch * kPatch * kCS;     // [9*64][16 dwords]
@@ -378,15 +375,10 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
       pre_p[k] = v;
     }
     const uint16_t* wsrc = wts + (static_cast<size_t>(cb) * nchunks + cc) * (9 * kTN * kCk16);
-    // (GEMM layout: row (tap, n) of this 32-channel chunk = 64-deep block tap * cin/64 + cc/2 of output block cb, row n, its
-    // lower or upper 32 channels)
-    const uint16_t* gsrc = wts + (static_cast<size_t>(cb) * 9 * (cin / 64) + (cc >> 1)) * (64 * 64) + (cc & 1) * 32;
 #pragma unroll
     for (int k = 0; k < kFP; ++k) {
       const int i = tid + k * kThreads;
-      const int row = i >> 2;  // tap * 64 + n
-      pre_f[k] = gemm_layout ? *reinterpret_cast<const u32x4*>(gsrc + (static_cast<size_t>(row >> 6) * (cin / 64) * 64 + (row & 63)) * 64 + (i & 3) * 8)
-                             : *reinterpret_cast<const u32x4*>(wsrc + row * kCk16 + (i & 3) * 8);
+      pre_f[k] = *reinterpret_cast<const u32x4*>(wsrc + (i >> 2) * kCk16 + (i & 3) * 8);
     }
   };
   auto commit = [&]() {
@@ -445,7 +437,7 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const float t = acc[i][j][jj] + bv;
-        v[i][jj] = relu == 1 ? fmaxf(t, 0.0f) : relu == 2 ? t / (1.0f + expf(-t)) : t;
+        v[i][jj] = relu ? fmaxf(t, 0.0f) : t;
       }
     if (tap) {
 #pragma unroll
@@ -521,24 +513,12 @@ conv16_kernel(const uint16_t* __restrict__ in, int H, int W, int cin, int cout, 
       if (y >= Ho || x >= Wo) continue;
       const float4 lo = *reinterpret_cast<const float4*>(T + row * kET + piece * 8);
       const float4 hi = *reinterpret_cast<const float4*>(T + row * kET + piece * 8 + 4);
-      float v8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const size_t at = ((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + cb * kTN + piece * 8;
-      if (res) {
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + at);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint16_t b16 = static_cast<uint16_t>(rv[e >> 1] >> (16 * (e & 1)));
-          float rf;
-          if (KIND == kF16) { union { uint16_t u; _Float16 h; } c; c.u = b16; rf = static_cast<float>(c.h); }
-          else { union { uint32_t u; float f; } c; c.u = static_cast<uint32_t>(b16) << 16; rf = c.f; }
-          v8[e] += rf;
-        }
-      }
       u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = static_cast<uint32_t>(round16<KIND>(v8[2 * e])) | (static_cast<uint32_t>(round16<KIND>(v8[2 * e + 1])) << 16);
-      *reinterpret_cast<u32x4*>(out16 + at) = o;
+      o[0] = static_cast<uint32_t>(round16<KIND>(lo.x)) | (static_cast<uint32_t>(round16<KIND>(lo.y)) << 16);
+      o[1] = static_cast<uint32_t>(round16<KIND>(lo.z)) | (static_cast<uint32_t>(round16<KIND>(lo.w)) << 16);
+      o[2] = static_cast<uint32_t>(round16<KIND>(hi.x)) | (static_cast<uint32_t>(round16<KIND>(hi.y)) << 16);
+      o[3] = static_cast<uint32_t>(round16<KIND>(hi.z)) | (static_cast<uint32_t>(round16<KIND>(hi.w)) << 16);
+      *reinterpret_cast<u32x4*>(out16 + ((img * Ho + y) * static_cast<size_t>(Wo) + x) * cout + cb * kTN + piece * 8) = o;
     }
   }
 }
@@ -560,19 +540,19 @@ int pack_conv16_3x3(int kind, const float* w, const float* b, float* packed, siz
   return check_launch("pack_weights16_kernel");
 }
 int launch_conv16_3x3(int kind, const uint16_t* in, int64_t n, int h, int w, int cin, int cout, const uint16_t* w16,
-                      const float* bias, int relu, uint16_t* out, hipStream_t s, int gemm_layout, const uint16_t* res) {
+                      const float* bias, int relu, uint16_t* out, hipStream_t s) {
   const dim3 grid(static_cast<unsigned>(ceil_div(h, kTile) * ceil_div(w, kTile)), static_cast<unsigned>(cout / kTN),
                   static_cast<unsigned>(n));
   if (kind == SPR_F16) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<kF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(kConvLds));
     hipLaunchKernelGGL(conv16_kernel<kF16>, grid, dim3(kThreads), kConvLds, s, in, h, w, cin, cout, w16, bias, relu, 0, 0,
-                       reinterpret_cast<float*>(out), static_cast<float*>(nullptr), gemm_layout, res);
+                       reinterpret_cast<float*>(out), static_cast<float*>(nullptr));
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<kBF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(kConvLds));
     hipLaunchKernelGGL(conv16_kernel<kBF16>, grid, dim3(kThreads), kConvLds, s, in, h, w, cin, cout, w16, bias, relu, 0, 0,
-                       reinterpret_cast<float*>(out), static_cast<float*>(nullptr), gemm_layout, res);
+                       reinterpret_cast<float*>(out), static_cast<float*>(nullptr));
   }
   return check_launch("conv16_kernel");
 }
@@ -815,10 +795,10 @@ static int vgg_forward(spr_vgg16_plan* plan, const uint8_t* images, int64_t n, i
       const uint16_t* w16 = reinterpret_cast<const uint16_t*>(pk + st.w_off);
       if (plan->compute == SPR_F16)
         hipLaunchKernelGGL(conv16_kernel<kF16>, grid, dim3(kThreads), kConvLds, s, src16, h, w, st.cin, st.cout, w16,
-                           pk + st.b_off, st.relu, st.pool, last ? 1 : 0, dst, tap, 0, static_cast<const uint16_t*>(nullptr));
+                           pk + st.b_off, st.relu, st.pool, last ? 1 : 0, dst, tap);
       else
         hipLaunchKernelGGL(conv16_kernel<kBF16>, grid, dim3(kThreads), kConvLds, s, src16, h, w, st.cin, st.cout, w16,
-                           pk + st.b_off, st.relu, st.pool, last ? 1 : 0, dst, tap, 0, static_cast<const uint16_t*>(nullptr));
+                           pk + st.b_off, st.relu, st.pool, last ? 1 : 0, dst, tap);
       const int rc = check_launch("conv16_kernel");
       if (rc != SPR_OK) return rc;
     } else {
