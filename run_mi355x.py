@@ -33,7 +33,8 @@ def main(config_file: str = "run.toml") -> list[int]:
         # gallery features depend only on what is in `key`: keep them across runs when [mi355x].gallery_cache is set
         key = {"files": dataloader.shoeprint_files, "scale": dataloader.scales[cluster], "block": block,
                "crop": list(config["dataset"]["crop"]), "model": dict(config["model"]),
-               "weights": config["mi355x"].get("weights", "")}
+               "weights": config["mi355x"].get("weights", ""),
+               "extractor_dtype": config["mi355x"].get("extractor_dtype", "float32")}
         path = os.path.join(cache_dir, f"gallery_block{block}_cluster{cluster}.f32") if cache_dir else ""
         shoeprint_features = feature_cache.load_features(path, key) if path else None
         if shoeprint_features is None:

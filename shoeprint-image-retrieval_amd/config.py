@@ -46,6 +46,7 @@ class Mi355xConfig(TypedDict, total=False):
     max_prepared_gib: float
     weights: str
     gallery_cache: str  # directory for persisted gallery features (feature_cache.py); "" = off
+    extractor_dtype: str  # "float32" (the reference's arithmetic) | "bfloat16" | "float16": compute type of the extractor
 
 
 class Config(TypedDict, total=False):
@@ -56,7 +57,7 @@ class Config(TypedDict, total=False):
 
 
 MI355X_DEFAULTS: dict[str, Any] = {"dtype": "float32", "ncc_method": "auto", "max_prepared_gib": 0.0, "weights": "",
-                                   "gallery_cache": ""}
+                                   "gallery_cache": "", "extractor_dtype": "float32"}
 
 
 def normalise(raw: dict) -> Config:

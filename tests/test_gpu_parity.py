@@ -438,6 +438,30 @@ def test_run_driver_on_an_image_directory(tmp_path, capsys):
     assert got == want
 
 
+def test_run_driver_with_a_16bit_extractor_and_16bit_maps(tmp_path, capsys):
+    """run_mi355x.main with [mi355x] extractor_dtype = "bfloat16" and dtype = "bfloat16" (features extracted on the 16-bit matrix
+    cores, stored as bfloat16 for the scorer): runs end to end, uses a gallery cache of its own, and on this easy two-cluster
+    directory every query still ranks where the float32 run ranks it, give or take one place."""
+    import dataset_util
+    import run_mi355x
+
+    case = next(c for c in dataset_util.CASES if c["name"] == "wvu_split")
+    dataset_util.write_dataset(str(tmp_path), case)
+    toml = tmp_path / "run.toml"
+    base = (f'[dataset]\ndir = "{tmp_path}"\ntype = "WVU2019"\ncrop = {case["crop"]}\nn_processes = 3\nn_clusters = 2\n'
+            f'cluster_minimise_tolerance = 0.05\n[model]\ntype = "VGG16"\nclahe_clip_limit = 2.0\nclahe_tile_grid_size = [8, 8]\n'
+            f'start_block = 16\nend_block = 9\nskip_blocks = []\nminimum_dim = 120\nmaximum_dim = 200\n'
+            f'[comparison]\nn_processes = 2\n[mi355x]\ngallery_cache = "{tmp_path}/cache"\n')
+    toml.write_text(base)
+    exact = run_mi355x.main(str(toml))
+    toml.write_text(base + 'extractor_dtype = "bfloat16"\ndtype = "bfloat16"\n')
+    got = run_mi355x.main(str(toml))
+    out = capsys.readouterr().out
+    assert "rank-1:" in out and out.count("Gallery features from") == 0  # (the float32 cache is not reused: other key)
+    assert len(got) == len(exact) and max(abs(a - b) for a, b in zip(got, exact)) <= 1, (got, exact)
+    assert run_mi355x.main(str(toml)) == got and "Gallery features from" in capsys.readouterr().out
+
+
 def test_run_driver_with_the_reference_default_model(tmp_path, capsys):
     """The [model] and [comparison] sections of the reference's own run.toml - EfficientNetV2_M, start_block 6, end_block 4,
     block 5 skipped, rotated and scaled query variants - on a two-cluster image directory == dataloader -> oracle chain
