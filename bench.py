@@ -300,7 +300,6 @@ def main(argv=None):
     ap.add_argument("--noise", type=int, default=None, help="noise amplitude of the synthetic queries (default: the workload's)")
     ap.add_argument("--no-extractor", action="store_true")
     ap.add_argument("--max-prepared-gib", type=float, default=0.0, help="HBM budget of one prepared gallery chunk (default: automatic)")
-    ap.add_argument("--no-pipeline", action="store_true", help="matrix-core plans: prepare and score the gallery chunks in turn")
     ap.add_argument("--no-secondary", action="store_true", help="do not append the config-3 measurement to the default run")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--cpu-sample-queries", type=int, default=0)
@@ -446,28 +445,9 @@ def run_config(args, config_id, ctx, cpu, primary):
     # config 5: one HIP stream per feature layer (prepare + score chains overlap), joined by events before the fusion
     streams = [torch.cuda.Stream() for _ in layers] if (len(layers) > 1 and not args.emu) else None
 
-    # matrix-core plans (config 3): the gallery's preparation runs on a second stream beside the pair kernel of the chunk
-    # before it (NccScorer.score_gallery_pipelined): four chunks, two prepared buffers
-    pipelined = (not args.emu and len(layers) == 1 and plans[0].method == 4 and not args.no_pipeline and ng_local >= 64)
-    if pipelined:
-        chunks[0] = int(min(chunks[0], max(1, math.ceil(ng_local / 4))))
-        pgs[0] = None
-        pg_pair = [dev.empty_bytes(plans[0].gallery_item_bytes * chunks[0]) for _ in range(2)]
-
     def score_layer(k, record):
         (q, g), plan, chunk, pg, out = layers[k], plans[k], chunks[k], pgs[k], layer_scores[k]
         pq = scorer.prepare_queries(plan, q)
-        if pipelined:
-            def around(kc, call):
-                if not record:
-                    return call()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                call()
-                e1.record()
-                pair_events.append((e0, e1, nq * min(chunk, ng_local - kc * chunk)))
-            scorer.score_gallery_pipelined(plan, pq, nq, g, out, ng_local, 0, chunk, pg_pair, around_score=around)
-            return
         for start in range(0, ng_local, chunk):
             n = min(chunk, ng_local - start)
             scorer.prepare_gallery(plan, dev.narrow0(g, start, n), out=pg)
@@ -664,7 +644,7 @@ def run_config(args, config_id, ctx, cpu, primary):
                    "method": {1: "fft", 2: "direct", 4: "mfma"}[plan0.method], "fft_grid": list(plan0.fft_size),
                    "gallery_chunk": chunks[0], "gallery_chunks_per_step": math.ceil(ng_local / chunks[0]),
                    "storage": storage, "parallelism": f"gallery-shard x{world}",
-                   "streams": len(streams) if streams else (2 if pipelined else 1)},
+                   "streams": len(streams) if streams else 1},
         "rank1": round(parse_results.rank1(ranks), 4), "mAP": round(parse_results.mean_average_precision(ranks), 4),
         "mean_rank": round(float(np.mean(ranks)), 2),
     }

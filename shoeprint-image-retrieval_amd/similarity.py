@@ -196,40 +196,6 @@ class NccScorer:
                                     self.dev.narrow0(scores, q0, qn), ng, start, accumulate_max)
         return scores
 
-    def score_gallery_pipelined(self, plan: _Plan, pq, nq: int, g_dev, scores, ld: int, col0: int, chunk: int, buffers,
-                                accumulate_max: bool = False, around_score=None):
-        """Prepare + score a gallery chunk by chunk with the preparation of chunk k + 1 running on a second HIP stream beside
-        the pair kernel of chunk k (two prepared buffers, events both ways).  Pays where the two kernels can share a CU: the
-        matrix-core pair kernel (one 256-lane workgroup and 135 KB of LDS per CU) leaves room for the wave-sized preparation
-        workgroups (7.4 KB each), so the gallery's preparation - a fifth of BASELINE config 3's step - runs under the scoring.
-        (The FFT pair kernels fill the LDS; there the plain loop is used.)  ``around_score(k, fn)`` lets the bench put its
-        timing events around every scoring call."""
-        dev = self.dev
-        main = dev.current()
-        if getattr(self, "_prep_stream", None) is None:
-            self._prep_stream = dev.new_stream()
-        side = self._prep_stream
-        ng = dev.shape(g_dev)[0]
-        starts = list(range(0, ng, chunk))
-        scored = [None] * len(starts)
-        dev.wait_stream(side, main)  # the features (and whatever filled the buffers before) are ready
-        for k, start in enumerate(starts):
-            n = min(chunk, ng - start)
-            pg = buffers[k % 2]
-            with dev.use(side):
-                if k >= 2:
-                    dev.wait_event(side, scored[k - 2])  # this buffer's previous chunk has been scored
-                self.prepare_gallery(plan, dev.narrow0(g_dev, start, n), out=pg)
-                prepared = dev.record_event(side)
-            dev.wait_event(main, prepared)
-            call = lambda: self.score_prepared(plan, pq, nq, pg, n, scores, ld, col0 + start, accumulate_max)
-            if around_score is not None:
-                around_score(k, call)
-            else:
-                call()
-            scored[k] = dev.record_event(main)
-        return scores
-
     def _offset(self, byte_buf, nbytes: int):
         return byte_buf if nbytes == 0 else self.dev.narrow0(byte_buf, nbytes, self.dev.shape(byte_buf)[0] - nbytes)
 
