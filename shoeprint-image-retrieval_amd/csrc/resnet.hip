@@ -68,19 +68,6 @@ rpack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
 
-__device__ __forceinline__ uint16_t sround_bf16(float v) {
-  union { float f; uint32_t u; } c;
-  c.f = v;
-  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
-  c.u += 0x7fffu + ((c.u >> 16) & 1u);
-  return static_cast<uint16_t>(c.u >> 16);
-}
-__device__ __forceinline__ uint16_t sround_f16(float v) {
-  union { _Float16 h; uint16_t u; } c;
-  c.h = static_cast<_Float16>(v);
-  return c.u;
-}
-
 // ---------------------------------------------------------------- stem: 7x7 s2 p3, 3 -> 64, pre-processing + ReLU fused
 // grid = (tiles of 8x8 output pixels, images); out NHWC [n][Ho][Wo][64]
 __global__ void __launch_bounds__(kThreads)
@@ -138,7 +125,7 @@ stem_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels, f
       const float v = relu ? fmaxf(acc[i], 0.0f) : acc[i];
       const size_t at = ((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + n;
       if (kind16 == 0) out[at] = v;
-      else reinterpret_cast<uint16_t*>(out)[at] = kind16 == SPR_F16 ? sround_f16(v) : sround_bf16(v);
+      else reinterpret_cast<uint16_t*>(out)[at] = kind16 == SPR_F16 ? round_f16(v) : round_bf16(v);
     }
   }
 }
@@ -281,34 +268,6 @@ conv_gemm_kernel(const float* __restrict__ in, int n_img, int H, int W, int cin,
 constexpr int kHM = 128, kHN = 64, kHK = 64;
 constexpr int kHRowDw = 32;  // dwords per LDS row (128 bytes)
 
-__host__ __device__ inline uint16_t rround_bf16(float v) {
-  union { float f; uint32_t u; } c;
-  c.f = v;
-  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
-  c.u += 0x7fffu + ((c.u >> 16) & 1u);
-  return static_cast<uint16_t>(c.u >> 16);
-}
-template <int KIND>
-__device__ __forceinline__ uint16_t rround16(float v) {
-  if (KIND == SPR_F16) {
-    union { _Float16 h; uint16_t u; } c;
-    c.h = static_cast<_Float16>(v);
-    return c.u;
-  }
-  return rround_bf16(v);
-}
-template <int KIND>
-__device__ __forceinline__ float rvalue16(uint16_t b) {
-  if (KIND == SPR_F16) {
-    union { uint16_t u; _Float16 h; } c;
-    c.u = b;
-    return static_cast<float>(c.h);
-  }
-  union { uint32_t u; float f; } c;
-  c.u = static_cast<uint32_t>(b) << 16;
-  return c.f;
-}
-
 // GEMM convs of a 16-bit plan: [cout/64][K/64][n:64][k:64] float16 / bfloat16, K index = tap * cin + c; bias f32
 template <int KIND>
 __global__ void __launch_bounds__(kThreads)
@@ -324,7 +283,7 @@ rpack16_kernel(const float* __restrict__ w, const float* __restrict__ b, float* 
     const int c = static_cast<int>((i / taps) % cin);
     const int n = static_cast<int>(i / (static_cast<size_t>(taps) * cin));
     const int k = tap * cin + c;
-    dst16[((static_cast<size_t>(n / kHN) * chunks + k / kHK) * kHN + n % kHN) * kHK + k % kHK] = rround16<KIND>(w[i]);
+    dst16[((static_cast<size_t>(n / kHN) * chunks + k / kHK) * kHN + n % kHN) * kHK + k % kHK] = round16<KIND>(w[i]);
   }
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < cout; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
@@ -388,7 +347,7 @@ rstem16_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, fl
     const int k = i / 64, n = i % 64;  // k = tap * 3 + c
     float v = 0.0f;
     if (k < F::KREAL) v = w[(static_cast<size_t>(n) * 3 + k % 3) * F::TAPS + k / 3];  // torch layout [n][c][ky][kx]
-    dst[(static_cast<size_t>(k / 8) * 64 + n) * 8 + k % 8] = rround16<KIND>(v);
+    dst[(static_cast<size_t>(k / 8) * 64 + n) * 8 + k % 8] = round16<KIND>(v);
   }
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < 64; i += gridDim.x * kThreads) packed[b_off + i] = b[i];
 }
@@ -437,7 +396,7 @@ stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels,
         const float u = static_cast<float>(in_channels == 1 ? images[pix] : images[pix * 3 + c]);
         v = (u / 255.0f - mean[c]) * istd[c];
       }
-      patch[i * 3 + c] = rround16<KIND>(v);
+      patch[i * 3 + c] = round16<KIND>(v);
     }
   }
   if (tid == 0) patch[kPatchElems] = 0;
@@ -505,7 +464,7 @@ stem16_kernel(const uint8_t* __restrict__ images, int H, int W, int in_channels,
       // relu: activation code (0 none, 1 ReLU, 2 SiLU)
       const float a0 = relu == 1 ? fmaxf(v[2 * e], 0.0f) : relu == 2 ? v[2 * e] / (1.0f + expf(-v[2 * e])) : v[2 * e];
       const float a1 = relu == 1 ? fmaxf(v[2 * e + 1], 0.0f) : relu == 2 ? v[2 * e + 1] / (1.0f + expf(-v[2 * e + 1])) : v[2 * e + 1];
-      o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+      o[e] = static_cast<uint32_t>(round16<KIND>(a0)) | (static_cast<uint32_t>(round16<KIND>(a1)) << 16);
     }
     *reinterpret_cast<u32x4*>(out + ((img * Ho + oy) * static_cast<size_t>(Wo) + ox) * 64 + ss * 8) = o;
   }
@@ -589,9 +548,9 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
           u32x4 r;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float lo = rvalue16<KIND>(static_cast<uint16_t>(ra[k][e] & 0xffffu)) * f[2 * e];
-            const float hi = rvalue16<KIND>(static_cast<uint16_t>(ra[k][e] >> 16)) * f[2 * e + 1];
-            r[e] = static_cast<uint32_t>(rround16<KIND>(lo)) | (static_cast<uint32_t>(rround16<KIND>(hi)) << 16);
+            const float lo = value16<KIND>(static_cast<uint16_t>(ra[k][e] & 0xffffu)) * f[2 * e];
+            const float hi = value16<KIND>(static_cast<uint16_t>(ra[k][e] >> 16)) * f[2 * e + 1];
+            r[e] = static_cast<uint32_t>(round16<KIND>(lo)) | (static_cast<uint32_t>(round16<KIND>(hi)) << 16);
           }
           ra[k] = r;
         }
@@ -670,7 +629,7 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
           if (chn >= creal) continue;
           float v = T[row * kHT + c];
           if (relu == 2) v = v / (1.0f + expf(-v));
-          if (res) v += rvalue16<KIND>(res[static_cast<size_t>(m) * cout + chn]);
+          if (res) v += value16<KIND>(res[static_cast<size_t>(m) * cout + chn]);
           if (relu == 1) v = fmaxf(v, 0.0f);
           out32[(img * creal + chn) * plane + pix] = v;
         }
@@ -692,13 +651,13 @@ conv_gemm16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int
         if (res) {
           const u32x4 rv = *reinterpret_cast<const u32x4*>(res + at);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rvalue16<KIND>(static_cast<uint16_t>(rv[e >> 1] >> (16 * (e & 1))));
+          for (int e = 0; e < 8; ++e) v[e] += value16<KIND>(static_cast<uint16_t>(rv[e >> 1] >> (16 * (e & 1))));
         }
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a0 = relu == 1 ? fmaxf(v[2 * e], 0.0f) : v[2 * e], a1 = relu == 1 ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
-          o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+          o[e] = static_cast<uint32_t>(round16<KIND>(a0)) | (static_cast<uint32_t>(round16<KIND>(a1)) << 16);
         }
         *reinterpret_cast<u32x4*>(out + at) = o;
       }
@@ -861,13 +820,13 @@ enet_dw16_kernel(const uint16_t* __restrict__ in, int n_img, int H, int W, int C
         const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          acc[e] = fmaf(rvalue16<KIND>(static_cast<uint16_t>(v[e >> 1] >> (16 * (e & 1)))), wv[e], acc[e]);
+          acc[e] = fmaf(value16<KIND>(static_cast<uint16_t>(v[e >> 1] >> (16 * (e & 1)))), wv[e], acc[e]);
       }
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float a0 = acc[2 * e] / (1.0f + expf(-acc[2 * e])), a1 = acc[2 * e + 1] / (1.0f + expf(-acc[2 * e + 1]));
-      o[e] = static_cast<uint32_t>(rround16<KIND>(a0)) | (static_cast<uint32_t>(rround16<KIND>(a1)) << 16);
+      o[e] = static_cast<uint32_t>(round16<KIND>(a0)) | (static_cast<uint32_t>(round16<KIND>(a1)) << 16);
     }
     *reinterpret_cast<u32x4*>(out + i * 8) = o;
   }
@@ -886,7 +845,7 @@ enet_pool16_kernel(const uint16_t* __restrict__ in, int HW, int C, float* __rest
   for (int p = r; p < HW; p += 32) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(p) * C);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] += rvalue16<KIND>(static_cast<uint16_t>(v[e >> 1] >> (16 * (e & 1))));
+    for (int e = 0; e < 8; ++e) s[e] += value16<KIND>(static_cast<uint16_t>(v[e >> 1] >> (16 * (e & 1))));
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[r][g8 * 8 + e] = s[e];

@@ -130,6 +130,34 @@ __device__ __forceinline__ float load_feature(const void* base, size_t idx, int 
   return static_cast<float>(v.h);
 }
 
+// float32 -> float16 / bfloat16 bit pattern, round to nearest even (what a stored 16-bit activation or weight of the 16-bit
+// extractor plans holds), and back.  KIND = SPR_F16 | SPR_BF16.
+__host__ __device__ inline uint16_t round_bf16(float v) {
+  union { float f; uint32_t u; } c;
+  c.f = v;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN
+  c.u += 0x7fffu + ((c.u >> 16) & 1u);                    // ties to even
+  return static_cast<uint16_t>(c.u >> 16);
+}
+__device__ __forceinline__ uint16_t round_f16(float v) {
+  union { _Float16 h; uint16_t u; } c;
+  c.h = static_cast<_Float16>(v);  // v_cvt_f16_f32: round to nearest even
+  return c.u;
+}
+template <int KIND>
+__device__ __forceinline__ uint16_t round16(float v) { return KIND == SPR_F16 ? round_f16(v) : round_bf16(v); }
+template <int KIND>
+__device__ __forceinline__ float value16(uint16_t b) {
+  if (KIND == SPR_F16) {
+    union { uint16_t u; _Float16 h; } c;
+    c.u = b;
+    return static_cast<float>(c.h);
+  }
+  union { uint32_t u; float f; } c;
+  c.u = static_cast<uint32_t>(b) << 16;
+  return c.f;
+}
+
 // Workgroup reductions over the launch's work-items (a multiple of 64); `scratch` holds one value per wave.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

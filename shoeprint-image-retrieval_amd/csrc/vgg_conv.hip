@@ -44,21 +44,6 @@ constexpr int kCk16 = 32;       // 16-bit matrix cores: input channels per chunk
 // (round to nearest even), bias / ReLU / pool and the last layer's output in f32.
 enum { kF32 = SPR_F32, kF16 = SPR_F16, kBF16 = SPR_BF16 };
 
-__host__ __device__ inline uint16_t round_bf16(float v) {
-  union { float f; uint32_t u; } c;
-  c.f = v;
-  if ((c.u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN
-  c.u += 0x7fffu + ((c.u >> 16) & 1u);                    // round to nearest, ties to even
-  return static_cast<uint16_t>(c.u >> 16);
-}
-__device__ __forceinline__ uint16_t round_f16(float v) {
-  union { _Float16 h; uint16_t u; } c;
-  c.h = static_cast<_Float16>(v);  // v_cvt_f16_f32: round to nearest even
-  return c.u;
-}
-template <int KIND>
-__device__ __forceinline__ uint16_t round16(float v) { return KIND == kF16 ? round_f16(v) : round_bf16(v); }
-
 struct Stage {
   int cin, cout;
   int relu, pool;
