@@ -139,6 +139,11 @@ def test_emu_multi_layer_pipeline():
     ec.check_multi_layer_pipeline(HostDevice(), emu_library(), emu_scorer("fft"), hw=(40, 32), n_gallery=5, n_queries=2, batch=2)
 
 
+def test_emu_multi_layer_pipeline_16bit_extractor():
+    ec.check_multi_layer_pipeline(HostDevice(), emu_library(), emu_scorer("fft"), hw=(40, 32), n_gallery=4, n_queries=2, batch=2,
+                                  compute="bfloat16")
+
+
 def test_emu_rgb_route():
     ec.check_rgb_route(HostDevice(), emu_library())
 

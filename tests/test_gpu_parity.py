@@ -370,6 +370,9 @@ def test_multi_layer_pipeline(torch_dev, lib, fft_scorer):
     import extractor_cases as ec
 
     ec.check_multi_layer_pipeline(torch_dev, lib, fft_scorer, hw=(128, 96), taps=(16, 23, 30), n_gallery=9, n_queries=4, batch=4)
+    for compute in ("bfloat16", "float16"):
+        ec.check_multi_layer_pipeline(torch_dev, lib, fft_scorer, hw=(128, 96), taps=(16, 23, 30), n_gallery=9, n_queries=4,
+                                      batch=4, compute=compute)
 
 
 def test_rgb_route(torch_dev, lib):
