@@ -293,6 +293,141 @@ prep_mfma_kernel(NccGeom g, int is_query, const void* __restrict__ maps, unsigne
   }
 }
 
+// ---- gallery preparation of the equal-size instance (template = map = frame): one wave = TWO channels -------------------
+// The general kernel above spends ~7 000 SIMD cycles on a 336-pixel map, most of them in the summed-area tables built for maps
+// of any size.  With template = map every window is a corner window - rows [max(0, y - TH/2), min(TH, y + TH/2)), columns
+// likewise - so the two window sums are a prefix or a suffix in either direction and no table is needed:
+//   lane = (channel of the pair, row): its 12 pixels stay in registers; the column-range sums of its row (float64 prefix, 12
+//   values per table) go to LDS; 48 lanes = (table, channel, column) run down the 28 rows (prefix, then the row-range sum of
+//   every y) and write them back in place; the row lanes pick their 2 x 12 window sums up again and finish 1/sigma, the raw
+//   window sum and the pixel words.  Same statistics as prep_mfma_kernel (float64 sums of float32 values and float32 squares,
+//   similarity.py:57-62), formed in another order: a few ulp of float64 apart.  grid = (ceil(channels / 2), items), 64 lanes.
+template <class M, bool EXACT>
+__global__ void __launch_bounds__(64)
+prep_gallery_fixed_kernel(NccGeom g, const void* __restrict__ maps, unsigned char* __restrict__ prepared, size_t item_bytes) {
+  constexpr int H = M::TH, W = M::TW, N = M::NPOS;
+  static_assert(H <= 32 && W % 4 == 0 && 4 * W <= 64 && M::FH == M::TH, "one row per lane, two channels per wave");
+  __shared__ double tab[2][2][H][W];
+  const int lane = static_cast<int>(threadIdx.x), half = lane >> 5, row = lane & 31;
+  const int c = 2 * static_cast<int>(blockIdx.x) + half;
+  const size_t item = blockIdx.y;
+  const bool valid = row < H && c < g.channels;
+  const int cc = c < g.channels ? c : g.channels - 1, rr = row < H ? row : H - 1;
+  const uint16_t* raw = static_cast<const uint16_t*>(maps) +
+                        ((item * g.channels + cc) * static_cast<size_t>(g.g_h) + (rr + g.crop)) * g.g_w + g.crop;
+  unsigned bits[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) bits[k] = raw[k];
+  float v[W];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    v[k] = valid ? from_storage(bits[k], g.dtype) : 0.0f;
+    s += static_cast<double>(v[k]);
+  }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) s += shfl_xor(s, m);  // over the 32 lanes of this channel
+  float mean = static_cast<float>(s / static_cast<double>(N));
+  // exact shift (see prep_mfma_kernel): kappa = the mean in the storage type, taken if x - kappa is representable everywhere
+  float kappa = 0.0f;
+  if constexpr (EXACT) {
+    kappa = from_storage(to_storage(mean, g.dtype), g.dtype);
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float d = v[k] - kappa;
+      if (valid && from_storage(to_storage(d, g.dtype), g.dtype) != d) bad = 1;
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) bad |= shfl_xor(bad, m);
+    if (bad) kappa = 0.0f;
+  }
+  unsigned char* out_item = prepared + item * item_bytes;
+  float* eb = reinterpret_cast<float*>(out_item + static_cast<size_t>(cc) * M::kGChanBytes);
+  float* ebs = eb + N;
+  unsigned* hl = reinterpret_cast<unsigned*>(ebs + N);
+  float x0[W];
+  unsigned word[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    x0[k] = v[k] - mean;
+    if constexpr (EXACT) {
+      word[k] = (kappa == 0.0f ? bits[k] : to_storage(v[k] - kappa, g.dtype)) << 16;
+    } else {
+      const unsigned hi = bf16_round(x0[k]);
+      word[k] = (hi << 16) | bf16_round(x0[k] - bf16_value(hi));
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < W; k += 4)
+      *reinterpret_cast<u32x4*>(hl + row * W + k) = u32x4{word[k], word[k + 1], word[k + 2], word[k + 3]};
+  }
+  if constexpr (EXACT) {
+    mean -= kappa;  // from here on: the mean of the map as the matrix cores see it
+    if (valid && row == 0) {
+      float* means = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kGChanBytes) +
+                     static_cast<size_t>(N) * pad16(g.channels);
+      means[c] = mean;
+    }
+  }
+  // column-range sums of this row: window columns [max(0, x - W/2), min(W, x + W/2))
+  {
+    double p1[W + 1], p2[W + 1];
+    p1[0] = 0.0; p2[0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float sq = x0[k] * x0[k];  // np.square keeps float32 (similarity.py:57)
+      p1[k + 1] = p1[k] + static_cast<double>(valid ? x0[k] : 0.0f);
+      p2[k + 1] = p2[k] + static_cast<double>(valid ? sq : 0.0f);
+    }
+    if (row < H) {
+#pragma unroll
+      for (int x = 0; x < W; ++x) {
+        const int a = x - W / 2 > 0 ? x - W / 2 : 0, b = x + W / 2 < W ? x + W / 2 : W;
+        tab[0][half][row][x] = p1[b] - p1[a];
+        tab[1][half][row][x] = p2[b] - p2[a];
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < 4 * W) {  // (table, channel, column): down the rows
+    double* col = &tab[0][0][0][0] + (lane / W) * (H * W) + lane % W;
+    double P[H + 1];
+    P[0] = 0.0;
+#pragma unroll
+    for (int r = 0; r < H; ++r) P[r + 1] = P[r] + col[r * W];
+#pragma unroll
+    for (int y = 0; y < H; ++y) {
+      const int a = y - H / 2 > 0 ? y - H / 2 : 0, b = y + H / 2 < H ? y + H / 2 : H;
+      col[y * W] = P[b] - P[a];
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  const double inv_n = 1.0 / static_cast<double>(N);
+  const int y0 = row - H / 2 > 0 ? row - H / 2 : 0, y1 = row + H / 2 < H ? row + H / 2 : H;
+  float o_b[W], o_bs[W];
+#pragma unroll
+  for (int x = 0; x < W; ++x) {
+    const double s1 = tab[0][half][row][x], s2 = tab[1][half][row][x];
+    const float inv = inv_sigma_from_sums(s1, s2, inv_n);
+    o_b[x] = inv;
+    if constexpr (EXACT) {
+      const int xa = x - W / 2 > 0 ? x - W / 2 : 0, xb = x + W / 2 < W ? x + W / 2 : W;
+      const double si = s1 + static_cast<double>(mean) * static_cast<double>((y1 - y0) * (xb - xa));  // raw window sum
+      o_bs[x] = inv * static_cast<float>(si);
+    } else {
+      o_bs[x] = inv * static_cast<float>(s1);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < W; k += 4) {
+    *reinterpret_cast<float4*>(eb + row * W + k) = float4{o_b[k], o_b[k + 1], o_b[k + 2], o_b[k + 3]};
+    *reinterpret_cast<float4*>(ebs + row * W + k) = float4{o_bs[k], o_bs[k + 1], o_bs[k + 2], o_bs[k + 3]};
+  }
+}
+
 // ---- exact form: V[p][c] = b[c][p] * mean[c] of one gallery item, 32 channels per workgroup through an LDS tile (the prep
 // workgroups own one channel each: written from there, V would be 4-byte stores 4 KB apart).  grid = (channel blocks, items)
 template <class M>
@@ -736,11 +871,27 @@ static int launch_prep_mfma_m(const NccGeom& g, bool is_query, const void* maps,
   const size_t lds = align_up(64 + sizeof(float) * kMaxPix, 16) + 2 * sizeof(double) * kSatElems;
   const size_t item_bytes = is_query ? mfma_query_item_bytes(g) : mfma_gallery_item_bytes(g);
   constexpr bool kFixed = M::FH == M::TH;  // (the equal-size instance is only chosen for template = map = frame)
+  int rc;
+  static const bool general_prep = std::getenv("SPR_MFMA_PREP") && std::atoi(std::getenv("SPR_MFMA_PREP")) == 0;  // A/B switch
+  if constexpr (kFixed) {
+    if (!is_query && !general_prep) {  // the gallery of the equal-size instance: two channels per wave, no tables
+      auto fixed = g.mfma_exact ? prep_gallery_fixed_kernel<M, true> : prep_gallery_fixed_kernel<M, false>;
+      hipLaunchKernelGGL(fixed, dim3((g.channels + 1) / 2, static_cast<unsigned>(n)), dim3(64), 0, stream, g, maps,
+                         static_cast<unsigned char*>(prepared), item_bytes);
+      rc = check_launch("prep_gallery_fixed_kernel");
+      if (rc == SPR_OK && g.mfma_exact) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(vcol_mfma_kernel<M>), dim3((pad16(g.channels) + 31) / 32, static_cast<unsigned>(n)),
+                           dim3(kThreads), 0, stream, g.channels, static_cast<unsigned char*>(prepared), item_bytes);
+        rc = check_launch("vcol_mfma_kernel");
+      }
+      return rc;
+    }
+  }
   auto kernel = g.mfma_exact ? prep_mfma_kernel<M, true, kFixed> : prep_mfma_kernel<M, false, kFixed>;
   // one wave per (item, channel): maps of 336 pixels leave a 256-lane workgroup waiting at its ~20 barriers
   hipLaunchKernelGGL(kernel, dim3(g.channels, static_cast<unsigned>(n)), dim3(64), lds, stream, g, is_query ? 1 : 0, maps,
                      static_cast<unsigned char*>(prepared), item_bytes);
-  int rc = check_launch("prep_mfma_kernel");
+  rc = check_launch("prep_mfma_kernel");
   if (rc == SPR_OK && g.mfma_exact && !is_query) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(vcol_mfma_kernel<M>), dim3((pad16(g.channels) + 31) / 32, static_cast<unsigned>(n)),
                        dim3(kThreads), 0, stream, g.channels, static_cast<unsigned char*>(prepared), item_bytes);
