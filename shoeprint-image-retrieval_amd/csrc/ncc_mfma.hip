@@ -28,9 +28,18 @@
 #include "ncc_prep_common.h"
 
 // -DSPR_MFMA_ABL=n: timing ablations (wrong results), tools/ubench/ablate_mfma.sh.  1: no epilogues, 2: one fragment read per
-// period instead of one per step, 3: no staging of the next channel, 4: no reloads of the template fragments
+// period instead of one per step, 3: no staging of the next channel, 4: no reloads of the template fragments, 5: no barrier
+// per channel
 #ifndef SPR_MFMA_ABL
 #define SPR_MFMA_ABL 0
+#endif
+// -DSPR_MFMA_GROUPS=n: n vector instructions behind every MFMA of a fragment step (scheduler groups); 0: the compiler's order
+#ifndef SPR_MFMA_GROUPS
+#define SPR_MFMA_GROUPS 0
+#endif
+// fragment steps between the LDS read of a fragment and its MFMAs
+#ifndef SPR_MFMA_AHEAD
+#define SPR_MFMA_AHEAD 2
 #endif
 
 namespace spr {
@@ -636,7 +645,7 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
   constexpr int NIT = M::KS * M::TP;       // fragment steps per period
   constexpr int IT_STAGE = 4, kStageEvery = 2;  // channel c + 1 is written to LDS in eight parts, every other step from here
   static_assert(IT_STAGE + 7 * kStageEvery < NIT, "staging must end inside the period");
-  f32x2 sc_cur[4], sc_prev[4];             // {a, a * mean} of this lane's four queries, channels c and c - 1
+  f32x2 sc_cur[4], sc_prev[4], sc_ld[4];   // {a, a * mean} of this lane's four queries, channels c and c - 1; in flight
 #pragma unroll
   for (int r = 0; r < 4; ++r) sc_cur[r] = f32x2{0.f, 0.f};
   float ebv = 0.f, ebsv = 0.f;             // 1/sigma and S1/sigma of the tile whose epilogue is due
@@ -651,9 +660,10 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
     if (active) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        // (the loaded pair is first needed by the last steps of the period: its zeroing for the extra period waits until
+        // mid-period - done here, the select made every period start with a full memory latency in front of its first MFMA)
         sc_prev[r] = sc_cur[r];
-        const f32x2 v = buf_ld8(q_rs, sc_off[r], static_cast<unsigned>(c < g.channels ? c : last_c) * 8u);
-        sc_cur[r] = c < g.channels ? v : f32x2{0.f, 0.f};
+        sc_ld[r] = buf_ld8(q_rs, sc_off[r], static_cast<unsigned>(c < g.channels ? c : last_c) * 8u);
       }
       const float* eb_cur = reinterpret_cast<const float*>(buf_cur + M::kEbOff);
       const float* eb_prev = reinterpret_cast<const float*>(buf_prev + M::kEbOff);
@@ -691,7 +701,7 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
       };
       // fragment ring: the reads of step it + kAhead are issued before the MFMAs of step it (the scheduling fences keep
       // them there: left alone, the compiler sinks every read to just in front of its first use)
-      constexpr int kAhead = 2, kRing = 3;
+      constexpr int kAhead = SPR_MFMA_AHEAD, kRing = SPR_MFMA_AHEAD + 1;
       u32x4 fch[kRing], fcl[kRing], fph[kRing], fpl[kRing];
       auto issue = [&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
@@ -729,6 +739,11 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
           epilogue(tdone, !cur_chan, cur_chan ? c : c - 1);
         }
         if constexpr (tnext >= 0) { ebv = nb; ebsv = nbs; }
+        if constexpr (it == NIT / 2) {
+          static_assert(NIT / 2 < NIT - M::TP, "the current channel's weights are first used by the last sigma step");
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc_cur[r] = c < g.channels ? sc_ld[r] : f32x2{0.f, 0.f};
+        }
         if constexpr (SPR_MFMA_ABL != 3 && it >= IT_STAGE && it < IT_STAGE + 8 * kStageEvery && (it - IT_STAGE) % kStageEvery == 0) {
           stage_store_part(buf_next, std::integral_constant<int, (it - IT_STAGE) / kStageEvery>{});
           if constexpr (it == IT_STAGE + 7 * kStageEvery) stage_load(c2);
@@ -755,23 +770,35 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
         });
         // template row pairs nobody needs any more: the previous channel's (the slowest group has just used it) is
         // replaced by channel c + 1's, and at the end of the period the first ones of this channel by channel c + 2's
-        if constexpr (ph == M::TP - 1 && SPR_MFMA_ABL != 4) {
+        // All of them go to the other buffer: its first (PERIOD - lag) / 2 row pairs hold channel c - 1's, which no tile
+        // group reads in this period (the slowest one is at k-step (PERIOD - lag) / 2 when the period starts) - they are
+        // reloaded in the FIRST steps.  Nothing is requested in the last steps of a period: the memory counter is in order,
+        // so the first wait of the next period (for the staged pixels, requested half a period earlier) would sit out the
+        // latency of a load requested just before it.
+        if constexpr (SPR_MFMA_ABL != 4) {
           constexpr int lag = M::DY * (M::NTG - 1);
-          if constexpr (sg + M::PERIOD - lag < M::PERIOD) {
+          constexpr int kFree = (M::PERIOD - lag) / 2;
+          if constexpr (ph == M::TP - 1 && sg + M::PERIOD - lag < M::PERIOD) {
             constexpr int ks = (sg + M::PERIOD - lag) / 2;
             A[PAR ^ 1][ks] = load_a(c1, ks);
-          } else {
-            constexpr int ks = (sg - lag) / 2;
-            A[PAR][ks] = load_a(c2, ks);
+          } else if constexpr (ph == 0 && sg / 2 < kFree) {
+            A[PAR ^ 1][sg / 2] = load_a(c1, sg / 2);
           }
         }
+#if SPR_MFMA_GROUPS
+        // the step's vector instructions (epilogue, staging addresses) in groups behind one MFMA each, not in one run
+        static_for<0, M::NTG>([&](auto) {
+          sched_group<0x8, 1>();
+          sched_group<0x2, SPR_MFMA_GROUPS>();
+        });
+#endif
         sched_fence();
       });
     } else {
       stage_store(buf_next);
       stage_load(c2);
     }
-    __syncthreads();  // channel c + 1 is staged; nobody reads channel c - 1's image any more
+    if (SPR_MFMA_ABL != 5) __syncthreads();  // channel c + 1 is staged; nobody reads channel c - 1's image any more
     const int t0 = b_prev;
     b_prev = b_cur; b_cur = b_next; b_next = t0;
   };
