@@ -496,11 +496,21 @@ corr_mfma_kernel(int channels, int nq_here, int ng, const unsigned char* __restr
   f32x4 acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the operands of the next k-step are requested before the MFMAs of this one (plain loop: load, wait, multiply - 8.5 ms
+  // for config 3's gallery; so: 6.x)
+  float4 a_next = *reinterpret_cast<const float4*>(up);
+  float4 b_next[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) b_next[nt] = *reinterpret_cast<const float4*>(vp[nt]);
   for (int c0 = 0; c0 < cp; c0 += 16) {
-    const float4 a = *reinterpret_cast<const float4*>(up + c0);
+    const float4 a = a_next;
     float4 b[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const float4*>(vp[nt] + c0);
+    for (int nt = 0; nt < 4; ++nt) b[nt] = b_next[nt];
+    const int cn = c0 + 16 < cp ? c0 + 16 : c0;  // (the last step re-reads its own operands)
+    a_next = *reinterpret_cast<const float4*>(up + cn);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b_next[nt] = *reinterpret_cast<const float4*>(vp[nt] + cn);
     const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {

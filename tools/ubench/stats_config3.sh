@@ -19,5 +19,5 @@ for r in rows[:8]:
                 "avg_ms": round(float(r["AverageNs"]) / 1e6, 4)})
 json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --config 3 --no-cpu-baseline --no-extractor --steps 2 --warmup 1 "
                       "(three steps in the trace: one warm-up + two timed)", "kernels": out},
-          open("profiles/r02_config3_kernel_stats.json", "w"), indent=1)
+          open("gpurun_out/r03_config3_kernel_stats.json", "w"), indent=1)
 PY
