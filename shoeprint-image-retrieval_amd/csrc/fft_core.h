@@ -218,8 +218,14 @@ struct LdsTwiddles {
 
 // Every lane of the wave must call this together; `xbuf` is the group's exchange image
 // (GroupFft<E,TG>::kGroupElems complex values); it may be reused as soon as the function returns.
-template <int E, int TG, int DIR, class Tw, int SPL>
-__device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, const Tw& tw, cf* xbuf) {
+struct NoSink {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `sink(pp)` is called as soon as sub-transform set pp is complete (E >= TG): a caller that stores y[pp] there does not
+// hold it in registers through the remaining phases.
+template <int E, int TG, int DIR, class Tw, int SPL, class Sink = NoSink>
+__device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, const Tw& tw, cf* xbuf,
+                                          const Sink& sink = Sink{}) {
   using G = GroupFft<E, TG>;
   static_assert(SPL == G::SPL, "y must be [GroupFft<E,TG>::SPL][TG]");
   Dft<E, DIR>::run(x);
@@ -259,6 +265,7 @@ __device__ __forceinline__ void group_fft(cf (&x)[E], cf (&y)[SPL][TG], int t, c
     // 2.4), so work that idle lanes do not do is clock headroom for the others.
     if constexpr (E >= TG) {
       if (E % TG == 0 || G::out_valid(t, ph)) Dft<TG, DIR>::run(y[ph]);
+      sink(ph);
     }
   }
   if constexpr (E < TG) {

@@ -31,6 +31,9 @@
 #include "ncc_fft_cfg.h"
 #include "ncc_prep_common.h"
 
+#ifndef SPR_BIG_ABL
+#define SPR_BIG_ABL 0  // timing ablations of the workspace instance (wrong results): 1 no image stores, 2 image reads from one
+#endif                 // cached line set, 3 operands of channel 0 every channel
 namespace spr {
 namespace {
 
@@ -329,6 +332,10 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   cf* xbuf = reinterpret_cast<cf*>(lds + xbuf_off);
   cf* nyq = reinterpret_cast<cf*>(lds + nyq_off_lds);  // [0, NH): gallery column nw/2, [NH, 2NH): query's
   const int tid = static_cast<int>(threadIdx.x);
+  // LEAN (the workspace instance, 24-point column units on 512 lanes): nothing but the accumulators lives across a
+  // transform - twiddles from the LDS table at use, one row round's 1/sigma at a time, operands requested where they are
+  // multiplied.  With the prefetch state of the LDS instances (2 x 96 + 48 registers) the kernel spilled 345 registers.
+  constexpr bool LEAN = BIG;
   constexpr int NVR = GW::SPL * KW * 2;          // accumulators per lane and row round ...
   constexpr int NV = (NVR + 3) / 4 * 4;          // ... padded to whole 16-byte loads of 1/sigma
   constexpr int RC = C::RC;                      // column rounds per channel
@@ -358,8 +365,8 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
   const int p_part = rk - s_full * C::EH;
 
   // ---- prefetch state --------------------------------------------------------------------------
-  float4 nxt[PF][2 * H2];  // H2 x (2 complex of G), H2 x (2 complex of Q) per buffer
-  float4 inv_nxt[RR][NV / 4];
+  float4 nxt[PF][2 * H2];  // H2 x (2 complex of G), H2 x (2 complex of Q) per buffer (LEAN: unused)
+  float4 inv_nxt[LEAN ? 1 : RR][NV / 4];
   cf nyq_nxt[NYQ];
   auto issue_unit = [&](int c, int rc, float4 (&buf)[2 * H2]) {
     c = c > last_c ? last_c : c;  // the one-past-the-end prefetch re-reads the last channel (never used)
@@ -373,12 +380,18 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     }
   };
   auto issue_inv = [&](int c) {
+    if constexpr (LEAN) return;
     const float4* inv4 = reinterpret_cast<const float4*>(ginv + static_cast<size_t>(c) * g.inv_per_chan);
 #pragma unroll
-    for (int rr = 0; rr < RR; ++rr)
+    for (int rr = 0; rr < (LEAN ? 1 : RR); ++rr)
 #pragma unroll
       for (int i = 0; i < NV / 4; ++i)
         inv_nxt[rr][i] = rr < g.rounds_r ? inv4[(rr * (NV / 4) + i) * C::NT + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto issue_inv_round = [&](int c, int rr) {  // LEAN: one row round's weights, requested as the round starts
+    const float4* inv4 = reinterpret_cast<const float4*>(ginv + static_cast<size_t>(c) * g.inv_per_chan);
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) inv_nxt[0][i] = inv4[(rr * (NV / 4) + i) * C::NT + tid];
   };
   auto issue_nyq = [&](int c) {
     c = c > last_c ? last_c : c;
@@ -457,7 +470,8 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     for (int e = 0; e < NV; ++e) acc[r][e] = 0.0f;
 
   issue_nyq(0);
-  if constexpr (PF == RC) {
+  if constexpr (LEAN) {
+  } else if constexpr (PF == RC) {
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc) issue_unit(0, rc, nxt[rc]);
   } else {
@@ -482,7 +496,7 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
     // channel into registers (live only across the column pass); the row pass reads its table at use
     RegTwiddles<C::EH> twc_reg;
     const LdsTwiddles<C::TGH> twc_lds{twt_h, tc};
-    if constexpr (RC > 1) {
+    if constexpr (RC > 1 && !LEAN) {
 #pragma unroll
       for (int p = 0; p < C::EH; ++p) twc_reg.w[p] = twc_lds.get(p);
     }
@@ -496,14 +510,45 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
       const bool active = j < C::COLS;
       float4 (&buf)[2 * H2] = nxt[PF == RC ? rc : 0];
       cf z[C::EH], y[GH::SPL][C::TGH];
+      if constexpr (LEAN) {
+        // requested and consumed here, in pieces of kPiece register pairs per operand: no operand lives across a transform
+        // and at most 2 * kPiece 16-byte loads are in registers beside the products
+        constexpr int kPiece = 4;
+#if SPR_BIG_ABL == 3
+        const float4* gs4 = reinterpret_cast<const float4*>(gspec + static_cast<size_t>(c & 0) * C::kSpecPerChan);
+        const float4* qs4 = reinterpret_cast<const float4*>(qspec + static_cast<size_t>(c & 0) * C::kSpecPerChan);
+#else
+        const float4* gs4 = reinterpret_cast<const float4*>(gspec + static_cast<size_t>(c) * C::kSpecPerChan);
+        const float4* qs4 = reinterpret_cast<const float4*>(qspec + static_cast<size_t>(c) * C::kSpecPerChan);
+#endif
 #pragma unroll
-      for (int mm = 0; mm < H2; ++mm) {
-        const float4 a = buf[mm], b = buf[H2 + mm];
-        z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
-        z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
+        for (int m0 = 0; m0 < H2; m0 += kPiece) {
+          float4 a[kPiece], b[kPiece];
+#pragma unroll
+          for (int i = 0; i < kPiece; ++i) {
+            const size_t idx = (static_cast<size_t>(rc) * H2 + (m0 + i < H2 ? m0 + i : H2 - 1)) * C::NT + tid;
+            a[i] = gs4[idx];
+            b[i] = qs4[idx];
+          }
+#pragma unroll
+          for (int i = 0; i < kPiece; ++i) {
+            if (m0 + i < H2) {
+              z[2 * (m0 + i)] = cmul(cmake(a[i].x, a[i].y), cmake(b[i].x, b[i].y));
+              z[2 * (m0 + i) + 1] = cmul(cmake(a[i].z, a[i].w), cmake(b[i].z, b[i].w));
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mm = 0; mm < H2; ++mm) {
+          const float4 a = buf[mm], b = buf[H2 + mm];
+          z[2 * mm] = cmul(cmake(a.x, a.y), cmake(b.x, b.y));
+          z[2 * mm + 1] = cmul(cmake(a.z, a.w), cmake(b.z, b.w));
+        }
       }
       // operands of a later unit start flying now
-      if constexpr (PF == RC) issue_unit(c + 1, rc, buf);
+      if constexpr (LEAN) {
+      } else if constexpr (PF == RC) issue_unit(c + 1, rc, buf);
       else if (rc + 1 < RC) issue_unit(c, rc + 1, buf);
       else issue_unit(c + 1, 0, buf);
       if constexpr (RC * C::CPR != C::COLS) {  // surplus groups of the last round transform zeros
@@ -519,29 +564,35 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
           z[m] = pk_add_i(z[m], cmul(nyq[k1], nyq[C::NH + k1]));
         }
       }
-      if constexpr (RC > 1) group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_reg, cbuf);
-      else group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_lds, cbuf);
-      if (active) {
+      auto store_set = [&](int pp) {
+        const int p = tc + C::TGH * pp;
+        if (!active || ((C::EH % C::TGH != 0) && p >= C::EH)) return;  // surplus groups / idle stage-2 lanes
+#if SPR_BIG_ABL == 1
+        if (BIG && g.channels > 0) return;
+#endif
+        cf* col = R + j * rs + p;
 #pragma unroll
-        for (int pp = 0; pp < GH::SPL; ++pp) {
-          const int p = tc + C::TGH * pp;
-          if ((C::EH % C::TGH != 0) && p >= C::EH) continue;  // idle stage-2 lanes
-          cf* col = R + j * rs + p;
-#pragma unroll
-          for (int s = 0; s < C::TGH; ++s) {
-            if (s < s_full) col[C::EH * s] = y[pp][s];                      // compile-time
-            else if (s == s_full && p_part > 0) {
-              if (p < p_part) col[C::EH * s] = y[pp][s];                    // last, partial row block
-            }
+        for (int s = 0; s < C::TGH; ++s) {
+          if (s < s_full) col[C::EH * s] = y[pp][s];                      // compile-time
+          else if (s == s_full && p_part > 0) {
+            if (p < p_part) col[C::EH * s] = y[pp][s];                    // last, partial row block
           }
         }
+      };
+      if constexpr (LEAN) {  // every sub-transform set leaves its registers as soon as it is complete
+        group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_lds, cbuf, store_set);
+      } else {
+        if constexpr (RC > 1) group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_reg, cbuf);
+        else group_fft<C::EH, C::TGH, +1>(z, y, tc, twc_lds, cbuf);
+#pragma unroll
+        for (int pp = 0; pp < GH::SPL; ++pp) store_set(pp);
       }
     }
     __syncthreads();
     issue_inv(c);  // consumed after this channel's row transforms
     issue_nyq(c + 1);
     RegTwiddles<C::EW> twr_reg;  // row twiddles: same reasoning, live only across the row pass
-    if constexpr (RR > 1) {
+    if constexpr (RR > 1 && !LEAN) {
 #pragma unroll
       for (int p = 0; p < C::EW; ++p) twr_reg.w[p] = twr.get(p);
     }
@@ -549,13 +600,19 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       if (rr >= g.rounds_r) break;  // uniform: RR is the variant's compile-time maximum
+      if constexpr (LEAN) issue_inv_round(c, rr);
       int pr = rr * C::PPR + gr;
       if (pr >= pairs) pr = pairs - 1;  // duplicate work on surplus lanes; their 1/sigma slots are 0
       // W[k] = Ya[k] + i*Yb[k] for k = tr + TGW*m, built from the stored half spectrum (columns 0..nw/2-1;
       // column nw/2 rides in the imaginary part of column 0).  Which form applies is a compile-time
       // property of the register index m, except for lane tr == 0 of the two registers holding k = 0, nw/2.
+#if SPR_BIG_ABL == 2
+      const cf* direct = BIG ? R + 2 * (tid & 63) - 0 * rs : R + tr * rs + 2 * pr;
+      const cf* mirror = BIG ? R + 2 * (tid & 63) - 0 * rs : R + (C::TGW - tr) * rs + 2 * pr;
+#else
       const cf* direct = R + tr * rs + 2 * pr;             // column k          (k < nw/2)
       const cf* mirror = R + (C::TGW - tr) * rs + 2 * pr;  // column nw - k     (k > nw/2), from m = EW-1 down
+#endif
       cf wv[C::EW], y[GW::SPL][C::TGW];
 #pragma unroll
       for (int m = 0; m < C::EW; ++m) {
@@ -574,9 +631,9 @@ pair_fft_kernel(PairArgs g, const unsigned char* __restrict__ pq, size_t q_item_
           wv[m] = pk_conj_add_i(cmake(ab.x, ab.y), cmake(ab.z, ab.w));  // conj(Ya) + i*conj(Yb)
         }
       }
-      if constexpr (RR > 1) group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr_reg, rbuf);
+      if constexpr (RR > 1 && !LEAN) group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr_reg, rbuf);
       else group_fft<C::EW, C::TGW, +1>(wv, y, tr, twr, rbuf);
-      const float* ivf = reinterpret_cast<const float*>(inv_nxt[rr]);
+      const float* ivf = reinterpret_cast<const float*>(inv_nxt[LEAN ? 0 : rr]);
 #pragma unroll
       for (int pp = 0; pp < GW::SPL; ++pp) {
 #pragma unroll
@@ -794,7 +851,8 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
       if (static_cast<size_t>(team_size) * 8 > slots) team_size = static_cast<int>(slots / 8);
     }
     {
-      const int strips = ceil_div(static_cast<int>(nq), 16);
+      const int strip_max = env_int("SPR_NCC_STRIP_Q", 16) > 0 ? env_int("SPR_NCC_STRIP_Q", 16) : 16;
+      const int strips = ceil_div(static_cast<int>(nq), strip_max);
       a.team_size = team_size;
       a.strips = strips;
       a.strip_q = ceil_div(static_cast<int>(nq), strips);
@@ -802,8 +860,8 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
       a.epochs_full = static_cast<int>((static_cast<int64_t>(a.strip_q) * ng + team_size - 1) / team_size);
       const int q_last = static_cast<int>(nq) - (a.strips - 1) * a.strip_q;
       a.epochs_total = (a.strips - 1) * a.epochs_full + static_cast<int>((static_cast<int64_t>(q_last) * ng + team_size - 1) / team_size);
-      a.sync_polls = BIG ? 0 : env_int("SPR_NCC_TEAM_POLLS", 256);
-      a.sync_every = BIG ? 0 : env_int("SPR_NCC_TEAM_EVERY", 32);
+      a.sync_polls = env_int("SPR_NCC_TEAM_POLLS", BIG ? 0 : 256);
+      a.sync_every = env_int("SPR_NCC_TEAM_EVERY", BIG ? 0 : 32);
       if (a.sync_every < 0) a.sync_every = 0;
       grid = 8u * static_cast<unsigned>(team_size);
       if (hipMemsetAsync(team_sync, 0, sizeof(unsigned) * kTeamCounters, stream) != hipSuccess) {
@@ -836,6 +894,10 @@ int pair_launch(const NccGeom& g, const void* pq, int64_t nq, const void* pg, in
   return SPR_OK;
 }
 
+// The workspace instance keeps its accumulators in registers beside 24-point column units: every accumulator it does not
+// need is a register it does not spill.  Tuned variant 9 x 4 (maps up to 256 x 108: conv3_3 of an 800 x 400 print), middle
+// variant 11 x 4 (up to 256 x 128), general variant for the rest.
+constexpr int kBigMidKw = 11, kBigMidRr = 4;
 // tuned variant: KW_A x RR_A with PFA prefetch buffers; general variant: everything kept, one buffer
 template <class C, int PFA, bool BIG, bool TEAM>
 int pair_tb(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void* pg, int64_t ng, float* scores,
@@ -844,6 +906,11 @@ int pair_tb(const NccGeom& g, bool tuned, const void* pq, int64_t nq, const void
   if (tuned)
     return pair_launch<C, C::RR_A, C::KW_A, PFA, rk_tuned<C>(), BIG, TEAM>(g, pq, nq, pg, ng, scores, ld, col0, accumulate,
                                                                            maps_out, tw_h, tw_w, team_sync, ws, stream);
+  if constexpr (BIG) {  // the workspace instance's middle variant (fill_geometry): the widest map of its grid, 4 row rounds
+    if (g.keep_w == kBigMidKw)
+      return pair_launch<C, kBigMidRr, kBigMidKw, 1, 0, BIG, TEAM>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out,
+                                                                   tw_h, tw_w, team_sync, ws, stream);
+  }
   return pair_launch<C, C::RR_B, C::KW_B, 1, 0, BIG, TEAM>(g, pq, nq, pg, ng, scores, ld, col0, accumulate, maps_out,
                                                            tw_h, tw_w, team_sync, ws, stream);
 }
@@ -914,7 +981,7 @@ const FftEntry kEntries[] = {
     entry6<Cfg<12, 16, 12, 8, 384, 5, 2, 1>>(),   // 192 x 96 on SIX waves per pair (ncc_pair6.hip): maps up to 126 x 64
     entry<Cfg<12, 16, 12, 8, 256, 5, 2>, 1>(),    // 192 x 96: conv3_3 of a 512x256 print; two workgroups per CU
     entry<Cfg<16, 16, 16, 8, 512, 4, 1>, 2>(),    // 256 x 128: 8 waves per workgroup, one workgroup per CU
-    entry<Cfg<24, 16, 12, 16, 512, 11, 4>, 1, true>(),  // 384 x 192: maps up to 256 x 128 (conv3_3 of a 1024x512 print,
+    entry<Cfg<24, 16, 12, 16, 512, 9, 4>, 1, true>(),  // 384 x 192: maps up to 256 x 128 (conv3_3 of a 1024x512 print,
                                                         // conv2_2 of 512x256); working set in the global workspace
 };
 #endif
@@ -958,6 +1025,7 @@ bool fill_geometry(NccGeom& g, const FftEntry& e, bool big) {
   g.tight = tuned ? 1 : 0;
   g.keep_w = tuned ? e.kw_a : e.kw_b;
   if (!tuned && (kw_need > e.kw_b || g.rounds_r > e.rr_b)) return false;
+  if (big && !tuned && kw_need <= kBigMidKw && g.rounds_r <= kBigMidRr && kBigMidKw < e.kw_b) g.keep_w = kBigMidKw;
   g.nv = (e.spl_w * g.keep_w * 2 + 3) / 4 * 4;
   g.spec_per_chan = e.spec_per_chan;
   g.inv_per_chan = g.rounds_r * g.nv * e.nt;

@@ -350,6 +350,16 @@ def check_big_mode(make_scorer, monkeypatch, full):
     got = sc.score_matrix(q, g)
     ref = oracle.similarity_matrix(q, g, precise=True)
     np.testing.assert_allclose(got, ref, atol=TIGHT, rtol=0)
+    if not full:
+        return
+    # the instance's other two accumulator layouts: maps wider than 108 columns (11 kept outputs per row transform) and a
+    # search map taller than 256 rows under a smaller template (five row rounds: the general variant)
+    for (c, qh, qw, gh, gw) in ((2, 200, 124, 200, 124), (1, 150, 60, 280, 100)):
+        sc = make_scorer()
+        assert sc.plan(c, (qh, qw), (gh, gw)).fft_size == (384, 192)
+        q = [synth.gallery_features(63, 50 + i, c, qh, qw) for i in range(2)]
+        g = [synth.gallery_features(63, i, c, gh, gw) for i in range(2)]
+        np.testing.assert_allclose(sc.score_matrix(q, g), oracle.similarity_matrix(q, g, precise=True), atol=TIGHT, rtol=0)
 
 
 def check_sparse_channels(scorer, c=5):
