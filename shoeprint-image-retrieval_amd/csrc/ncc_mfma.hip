@@ -437,6 +437,154 @@ prep_gallery_fixed_kernel(NccGeom g, const void* __restrict__ maps, unsigned cha
   }
 }
 
+// ---- gallery preparation of the general instance: the same two-channels-per-wave scheme for ANY template on any map of the
+// frame.  The windows are no longer corner windows (rows [y - th/2, y - th/2 + th) clipped to the map), so the range sums are
+// differences of INCLUSIVE prefixes picked at run-time positions: the prefixes go through LDS (a register array cannot be
+// indexed at run time without scratch) - along the row (written and read back by the same lane), then down the columns.
+template <class M, bool EXACT>
+__global__ void __launch_bounds__(64)
+prep_gallery_wave_kernel(NccGeom g, const void* __restrict__ maps, unsigned char* __restrict__ prepared, size_t item_bytes) {
+  constexpr int H = M::TH, W = M::TW, N = M::NPOS;
+  static_assert(H <= 32 && W % 4 == 0 && 4 * W <= 64, "one row per lane, two channels per wave");
+  __shared__ double tab[2][2][H][W];
+  const int th = g.th, tw = g.tw, ih = g.ih, iw = g.iw;
+  const int lane = static_cast<int>(threadIdx.x), half = lane >> 5, row = lane & 31;
+  const int c = 2 * static_cast<int>(blockIdx.x) + half;
+  const size_t item = blockIdx.y;
+  const bool chan_ok = c < g.channels;
+  const bool in_map = row < ih && chan_ok;  // this lane holds a row of the map
+  const int cc = chan_ok ? c : g.channels - 1, rr = row < ih ? row : ih - 1;
+  const uint16_t* raw = static_cast<const uint16_t*>(maps) +
+                        ((item * g.channels + cc) * static_cast<size_t>(g.g_h) + (rr + g.crop)) * g.g_w + g.crop;
+  unsigned bits[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) bits[k] = raw[k < iw ? k : iw - 1];
+  float v[W];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    v[k] = in_map && k < iw ? from_storage(bits[k], g.dtype) : 0.0f;
+    s += static_cast<double>(v[k]);
+  }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) s += shfl_xor(s, m);
+  float mean = static_cast<float>(s / static_cast<double>(ih * iw));
+  float kappa = 0.0f;
+  if constexpr (EXACT) {
+    kappa = from_storage(to_storage(mean, g.dtype), g.dtype);
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float d = v[k] - kappa;
+      if (in_map && k < iw && from_storage(to_storage(d, g.dtype), g.dtype) != d) bad = 1;
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) bad |= shfl_xor(bad, m);
+    if (bad) kappa = 0.0f;
+  }
+  unsigned char* out_item = prepared + item * item_bytes;
+  float* eb = reinterpret_cast<float*>(out_item + static_cast<size_t>(cc) * M::kGChanBytes);
+  float* ebs = eb + N;
+  unsigned* hl = reinterpret_cast<unsigned*>(ebs + N);
+  float x0[W];
+  unsigned word[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const bool inside = in_map && k < iw;
+    x0[k] = inside ? v[k] - mean : 0.0f;
+    if constexpr (EXACT) {
+      word[k] = inside ? (kappa == 0.0f ? bits[k] : to_storage(v[k] - kappa, g.dtype)) << 16 : 0u;
+    } else {
+      const unsigned hi = bf16_round(x0[k]);
+      word[k] = (hi << 16) | bf16_round(x0[k] - bf16_value(hi));
+    }
+  }
+  const bool frame_row = row < H && chan_ok;  // every row of the frame is written (zeros outside the map)
+  if (frame_row) {
+#pragma unroll
+    for (int k = 0; k < W; k += 4)
+      *reinterpret_cast<u32x4*>(hl + row * W + k) = u32x4{word[k], word[k + 1], word[k + 2], word[k + 3]};
+  }
+  if constexpr (EXACT) {
+    mean -= kappa;
+    if (chan_ok && row == 0) {
+      float* means = reinterpret_cast<float*>(out_item + static_cast<size_t>(g.channels) * M::kGChanBytes) +
+                     static_cast<size_t>(N) * pad16(g.channels);
+      means[c] = mean;
+    }
+  }
+  // inclusive prefixes along the row -> LDS -> the column-range sums of the row, back in place
+  if (row < H) {
+    double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float sq = x0[k] * x0[k];  // np.square keeps float32 (similarity.py:57)
+      r1 += static_cast<double>(x0[k]);
+      r2 += static_cast<double>(sq);
+      tab[0][half][row][k] = r1;
+      tab[1][half][row][k] = r2;
+    }
+    double c1[W], c2[W];
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+      int xa = x - tw / 2, xb = xa + tw;
+      xa = xa < 0 ? 0 : (xa > iw ? iw : xa);
+      xb = xb < 0 ? 0 : (xb > iw ? iw : xb);
+      const double hi1 = xb > 0 ? tab[0][half][row][xb - 1] : 0.0, lo1 = xa > 0 ? tab[0][half][row][xa - 1] : 0.0;
+      const double hi2 = xb > 0 ? tab[1][half][row][xb - 1] : 0.0, lo2 = xa > 0 ? tab[1][half][row][xa - 1] : 0.0;
+      c1[x] = hi1 - lo1;
+      c2[x] = hi2 - lo2;
+    }
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+      tab[0][half][row][x] = c1[x];
+      tab[1][half][row][x] = c2[x];
+    }
+  }
+  __syncthreads();
+  if (lane < 4 * W) {  // (table, channel, column): inclusive prefix down the rows, in place
+    double* col = &tab[0][0][0][0] + (lane / W) * (H * W) + lane % W;
+    double P[H];
+    double run = 0.0;
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      run += col[r * W];
+      P[r] = run;
+    }
+#pragma unroll
+    for (int r = 0; r < H; ++r) col[r * W] = P[r];
+  }
+  __syncthreads();
+  if (!frame_row) return;
+  const double inv_n = 1.0 / static_cast<double>(th * tw);
+  int y0 = row - th / 2, y1 = y0 + th;
+  y0 = y0 < 0 ? 0 : (y0 > ih ? ih : y0);
+  y1 = y1 < 0 ? 0 : (y1 > ih ? ih : y1);
+  float o_b[W], o_bs[W];
+#pragma unroll
+  for (int x = 0; x < W; ++x) {
+    const double s1 = (y1 > 0 ? tab[0][half][y1 - 1][x] : 0.0) - (y0 > 0 ? tab[0][half][y0 - 1][x] : 0.0);
+    const double s2 = (y1 > 0 ? tab[1][half][y1 - 1][x] : 0.0) - (y0 > 0 ? tab[1][half][y0 - 1][x] : 0.0);
+    const bool inside = row < ih && x < iw;
+    const float inv = inside ? inv_sigma_from_sums(s1, s2, inv_n) : 0.0f;
+    o_b[x] = inv;
+    if constexpr (EXACT) {
+      int xa = x - tw / 2, xb = xa + tw;
+      xa = xa < 0 ? 0 : (xa > iw ? iw : xa);
+      xb = xb < 0 ? 0 : (xb > iw ? iw : xb);
+      const double si = s1 + static_cast<double>(mean) * static_cast<double>((y1 - y0) * (xb - xa));  // raw window sum
+      o_bs[x] = inside ? inv * static_cast<float>(si) : 0.0f;
+    } else {
+      o_bs[x] = inside ? inv * static_cast<float>(s1) : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < W; k += 4) {
+    *reinterpret_cast<float4*>(eb + row * W + k) = float4{o_b[k], o_b[k + 1], o_b[k + 2], o_b[k + 3]};
+    *reinterpret_cast<float4*>(ebs + row * W + k) = float4{o_bs[k], o_bs[k + 1], o_bs[k + 2], o_bs[k + 3]};
+  }
+}
+
 // ---- exact form: V[p][c] = b[c][p] * mean[c] of one gallery item, 32 channels per workgroup through an LDS tile (the prep
 // workgroups own one channel each: written from there, V would be 4-byte stores 4 KB apart).  grid = (channel blocks, items)
 template <class M>
@@ -916,6 +1064,20 @@ static int launch_prep_mfma_m(const NccGeom& g, bool is_query, const void* maps,
       hipLaunchKernelGGL(fixed, dim3((g.channels + 1) / 2, static_cast<unsigned>(n)), dim3(64), 0, stream, g, maps,
                          static_cast<unsigned char*>(prepared), item_bytes);
       rc = check_launch("prep_gallery_fixed_kernel");
+      if (rc == SPR_OK && g.mfma_exact) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(vcol_mfma_kernel<M>), dim3((pad16(g.channels) + 31) / 32, static_cast<unsigned>(n)),
+                           dim3(kThreads), 0, stream, g.channels, static_cast<unsigned char*>(prepared), item_bytes);
+        rc = check_launch("vcol_mfma_kernel");
+      }
+      return rc;
+    }
+  }
+  if constexpr (!kFixed) {
+    if (!is_query && !general_prep) {  // the gallery of the general instance: the same scheme with run-time windows
+      auto wave = g.mfma_exact ? prep_gallery_wave_kernel<M, true> : prep_gallery_wave_kernel<M, false>;
+      hipLaunchKernelGGL(wave, dim3((g.channels + 1) / 2, static_cast<unsigned>(n)), dim3(64), 0, stream, g, maps,
+                         static_cast<unsigned char*>(prepared), item_bytes);
+      rc = check_launch("prep_gallery_wave_kernel");
       if (rc == SPR_OK && g.mfma_exact) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(vcol_mfma_kernel<M>), dim3((pad16(g.channels) + 31) / 32, static_cast<unsigned>(n)),
                            dim3(kThreads), 0, stream, g.channels, static_cast<unsigned char*>(prepared), item_bytes);
