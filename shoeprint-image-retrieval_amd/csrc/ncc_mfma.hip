@@ -89,7 +89,7 @@ struct MCfg {
   static constexpr int JS = (PR + 1) / 2 * 2 * RS;
   static constexpr int HL = 3 * JS;  // lo plane behind the hi plane
   static constexpr int kCopyBytes = 2 * HL;
-  static constexpr int kEbOff = kCopyBytes;                // float b[NPOS], (b*S1)[NPOS]
+  static constexpr int kEbOff = kCopyBytes;                // {b, b*S1}[NPOS] (float pairs)
   static constexpr int kDummyOff = kEbOff + 2 * 4 * NPOS;  // 16 bytes nobody reads: where masked-out stores go (no branches)
   static constexpr int kBufBytes = kDummyOff + 16;         // one channel; three buffers: channels c - 1 and c are read while
   static constexpr int kLdsBytes = 3 * kBufBytes;          // channel c + 1 is staged
@@ -733,12 +733,10 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
       if constexpr (!EXACT)
         *reinterpret_cast<uint16_t*>(buf + (held ? addr + M::HL : M::kDummyOff + 2)) = static_cast<uint16_t>(hl & 0xffffu);
     }
-    if constexpr (k == 0) {
-      float* eb = reinterpret_cast<float*>(buf + M::kEbOff);
-      eb[tid] = st_b[0];
-      eb[M::NPOS + tid] = st_bs[0];
-      eb[e1] = st_b[1];
-      eb[M::NPOS + e1] = st_bs[1];
+    if constexpr (k == 0) {  // the two epilogue weights of a pixel side by side: one 8-byte store here, one 8-byte read there
+      f32x2* eb = reinterpret_cast<f32x2*>(buf + M::kEbOff);
+      eb[tid] = f32x2{st_b[0], st_bs[0]};
+      eb[e1] = f32x2{st_b[1], st_bs[1]};
     }
   };
   auto stage_store = [&](unsigned char* buf) {
@@ -803,7 +801,7 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
   constexpr int NIT = M::KS * M::TP;       // fragment steps per period
   constexpr int IT_STAGE = 4, kStageEvery = 2;  // channel c + 1 is written to LDS in eight parts, every other step from here
   static_assert(IT_STAGE + 7 * kStageEvery < NIT, "staging must end inside the period");
-  f32x2 sc_cur[4], sc_prev[4], sc_ld[4];   // {a, a * mean} of this lane's four queries, channels c and c - 1; in flight
+  f32x2 sc_cur[4], sc_prev[4], sc_ld[4], sc_ld2[4];  // {a, a * mean} of this lane's four queries, channels c and c - 1; in flight
 #pragma unroll
   for (int r = 0; r < 4; ++r) sc_cur[r] = f32x2{0.f, 0.f};
   float ebv = 0.f, ebsv = 0.f;             // 1/sigma and S1/sigma of the tile whose epilogue is due
@@ -821,10 +819,16 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
         // (the loaded pair is first needed by the last steps of the period: its zeroing for the extra period waits until
         // mid-period - done here, the select made every period start with a full memory latency in front of its first MFMA)
         sc_prev[r] = sc_cur[r];
-        sc_ld[r] = buf_ld8(q_rs, sc_off[r], static_cast<unsigned>(c < g.channels ? c : last_c) * 8u);
+        if constexpr (PAR == 0) {  // (c is even here: one 16-byte load holds the pairs of channels c and c + 1)
+          const u32x4 v = buf_ld16v(q_rs, sc_off[r], static_cast<unsigned>(c < g.channels ? c : (last_c & ~1)) * 8u);
+          sc_ld[r] = f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+          sc_ld2[r] = f32x2{__uint_as_float(v[2]), __uint_as_float(v[3])};
+        } else {
+          sc_ld[r] = sc_ld2[r];
+        }
       }
-      const float* eb_cur = reinterpret_cast<const float*>(buf_cur + M::kEbOff);
-      const float* eb_prev = reinterpret_cast<const float*>(buf_prev + M::kEbOff);
+      const f32x2* eb_cur = reinterpret_cast<const f32x2*>(buf_cur + M::kEbOff);
+      const f32x2* eb_prev = reinterpret_cast<const f32x2*>(buf_prev + M::kEbOff);
       auto load_frag = [&](const unsigned char* buf, int ph, int s, int plane) {
         return *reinterpret_cast<const u32x4*>(buf + frag_base[ph] + s * M::RS + plane * M::HL);
       };
@@ -886,9 +890,9 @@ pair_mfma_kernel(MfmaArgs g, const unsigned char* __restrict__ pq, const unsigne
         constexpr int tnext = finished(it);
         float nb = 0.f, nbs = 0.f;
         if constexpr (tnext >= 0) {
-          const float* e = tnext < M::TP ? eb_cur : eb_prev;
-          nb = e[16 * tnext + col];
-          nbs = e[M::NPOS + 16 * tnext + col];
+          const f32x2 w = (tnext < M::TP ? eb_cur : eb_prev)[16 * tnext + col];
+          nb = w.x;
+          nbs = w.y;
         }
         sched_fence();
         if constexpr (tdone >= 0 && SPR_MFMA_ABL != 1) {
